@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- Mblocks/s of the hot path (MF::calcMotionBlockMatching) on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one whole pyramid (search + regulariser of every level + dense expansion) over one
+synthetic 4K frame pair per GPU (BASELINE.json configs[2]; configs[4] for N > 1: one pair per
+GPU, dense .flo fields gathered to rank 0 over RCCL).  Frames are resident in HBM before the
+timed region; the pyramid build (the reference's constructor, outside its own timed region,
+main_class.cpp:45-55) is not part of a step.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_SAD_PEAK_TOPS = 314.6            # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz x 4 abs-diff per v_sad_u8
+
+WORKLOADS = {
+    # name: (width, height, search_size, block_size, levels, description)
+    "cfg3": (3840, 2160, 80, 16, 4, "cfg3: 4K 3840x2160 synthetic pair, 16x16 blocks, +-32 spiral full search, "
+                                     "4-level pyramid, 8-neighbour regulariser (2 sweeps per block size 16..2)"),
+    "cfg2": (1920, 1080, 48, 16, 3, "cfg2: 1080p synthetic pair, 16x16 blocks, +-16, 3 levels"),
+    "cfg4": (3840, 2160, 72, 8, 4, "cfg4: 4K synthetic pair, 8x8 blocks, +-32, 4 levels"),
+    "cfg1": (584, 388, 30, 16, 3, "cfg1: RubberWhale-sized synthetic pair, 16x16 blocks, +-7, 3 levels"),
+}
+
+
+def level_blocks(pw, ph, block, levels):
+    return [((pw >> l) // block) * ((ph >> l) // block) for l in range(levels)]
+
+
+def cpu_baseline(f1, f2, search, block, levels, expect_flow):
+    """The oracle (CPU restatement, 1 thread, rebuilt here with -march=native) timed on the same pair."""
+    src = os.path.join(ROOT, "oracle", "bbme_oracle.c")
+    out = os.path.join(tempfile.mkdtemp(prefix="bbme_cpu_"), "liboracle_native.so")
+    subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-shared", "-ffp-contract=off",
+                           "-o", out, src, "-lm"])
+    from oracle import bbme_oracle as O
+    import ctypes as C
+    O._LIB_PATH = out            # load the native build instead of the portable one
+    O._lib = None
+    omf = O.OracleMF(f1, f2, [search] * levels, [block] * levels, use_cache=False)
+    t0 = time.perf_counter()
+    flow = omf.calc_motion_block_matching()
+    dt = time.perf_counter() - t0
+    omf.close()
+    parity = bool(np.array_equal(flow, expect_flow)) if expect_flow is not None else None
+    return dt, parity
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-iters", type=int, default=5)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
+
+    import torch
+    import torch.distributed as dist
+    import blockbasedmotionestimation_amd as bbme
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    w, h, search, block, levels, desc = WORKLOADS[args.workload]
+    f1, f2, _ = bbme.synth_pair(w, h, 1000 + 30 + rank, max_motion=24)      # one pair per GPU (weak scaling)
+    t1 = torch.from_numpy(f1).cuda()
+    t2 = torch.from_numpy(f2).cuda()
+    mf = bbme.MF(t1, t2, [search] * levels, [block] * levels, levels, device=local_rank, frames_on_device=True)
+    mf.synchronize()
+    pw, ph = mf.padded_width, mf.padded_height
+    blocks = level_blocks(pw, ph, block, levels)
+
+    # dense result as a torch view (for the gather); the ctx owns the memory
+    class _View:
+        pass
+    v = _View()
+    v.__cuda_array_interface__ = {"shape": (ph, pw, 2), "typestr": "<f4", "data": (mf.flow_device_ptr(), False),
+                                  "version": 2, "strides": None}
+    flow_t = torch.as_tensor(v, device=torch.device("cuda", local_rank))
+    gather_list = [torch.empty_like(flow_t) for _ in range(world)] if (world > 1 and rank == 0) else None
+    compute_done = torch.cuda.Event()
+
+    def step():
+        mf.estimate_async()                       # whole pyramid on the ctx stream, no host wait
+        if world > 1:
+            # hand the finished field to the current torch stream, gather the .flo fields on rank 0
+            mf.synchronize()
+            dist.gather(flow_t, gather_list, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        mf.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    result_flow = mf.get_flow() if rank == 0 else None
+
+    # per-kernel timing with HIP events on the ctx stream (eager launches, same kernels and data)
+    prof = None
+    if rank == 0:
+        mf.set_profiling(True)
+        acc = {}
+        for _ in range(args.profile_iters):
+            mf.estimate_async()
+            for k, val in mf.timings().items():
+                acc[k] = acc.get(k, 0.0) + val
+        mf.set_profiling(False)
+        prof = {k: val / args.profile_iters for k, val in acc.items()}
+
+    if rank == 0:
+        R = (search - block) >> 1
+        units = blocks[0] * world
+        value = units * args.steps / elapsed / 1e6
+        # dominant kernel: k_search_generic<B>, one launch per level.  Algorithmic bytes per block
+        # = B^2 + (B+2R)^2 + 8; "per launch" = mean over the `levels` launches of a pyramid.
+        bytes_per_block = block * block + (block + 2 * R) ** 2 + 8
+        search_bytes = sum(blocks) * bytes_per_block / levels
+        search_ms = prof["search_ms"] / levels
+        achieved = search_bytes / (search_ms * 1e-3) / 1e9
+        absdiff = sum(blocks) * (2 * R + 1) ** 2 * block * block / levels
+        out = {
+            "metric": "Mblocks/s (16x16, +-32 full search)", "value": round(value, 4), "unit": "Mblocks/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": desc, "pairs_per_step": world, "frame": [w, h], "padded": [pw, ph],
+                       "block": block, "search_range": R, "levels": levels,
+                       "blocks_level0": blocks[0], "blocks_all_levels": sum(blocks),
+                       "multi_gpu": "one pair per GPU, dense flow gathered to rank 0 (RCCL)" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "k_search_generic<%d> (mean of the %d per-level launches)" % (block, levels),
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "avg_launch_ms": round(search_ms, 5),
+                         "note": "kernel is integer-SAD VALU bound, not HBM bound (SURVEY 8d)",
+                         "valu_sad": {"achieved_Tabsdiff_s": round(absdiff / (search_ms * 1e-3) / 1e12, 3),
+                                      "peak_Tabsdiff_s": VALU_SAD_PEAK_TOPS,
+                                      "frac": round(absdiff / (search_ms * 1e-3) / 1e12 / VALU_SAD_PEAK_TOPS, 5)}},
+            "device_ms": {k: round(val, 4) for k, val in prof.items()},
+        }
+        if not args.no_cpu_baseline:
+            dt, parity = cpu_baseline(f1, f2, search, block, levels, result_flow)
+            out["cpu_baseline"] = {"value": round(blocks[0] / dt / 1e6, 5), "unit": "Mblocks/s", "cores": 1,
+                                   "kind": "port", "seconds": round(dt, 2),
+                                   "sample": "the same full %s pair, whole pyramid, oracle/bbme_oracle.c "
+                                             "(-O3 -march=native, 1 thread, no SAD cache)" % args.workload}
+            out["parity_vs_oracle"] = parity
+        print(json.dumps(out))
+    mf.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

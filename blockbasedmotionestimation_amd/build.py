@@ -1,0 +1,54 @@
+"""Builds libbbme.so (HIP kernels + C-ABI) in-tree for gfx950 with hipcc.
+
+    python -m blockbasedmotionestimation_amd.build [--force]
+
+hipcc cross-compiles without a GPU, so this also runs in the CPU-only container.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libbbme.so")
+SOURCES = ["bbme_host.cpp", "bbme_device.hip"]
+HEADERS = ["bbme_internal.hpp", "bbme_kernels.hpp", os.path.join(ROOT, "include", "bbme.h")]
+ARCH = "gfx950"
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm; set HIPCC=/path/to/hipcc)")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + \
+           [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-std=c++17", "-O3", "-fPIC", "-shared",
+           "-Wall", "-Wno-unused-function",
+           "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+           "-x", "hip"]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    cmd += ["-o", LIB + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,689 @@
+// bbme_device.hip -- context, launch sequence and the GPU half of the C-ABI (include/bbme.h).
+// Replaces the MF object of the reference (motion_framework.h:9-54): bbme_create + bbme_set_frames_*
+// are MF::MF, bbme_estimate is MF::calcMotionBlockMatching.  gfx950 only; no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "bbme_internal.hpp"
+#include "bbme_kernels.hpp"
+
+using namespace bbme;
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return bbme::fail(BBME_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                              __FILE__, __LINE__);                                             \
+    } while (0)
+
+namespace {
+
+struct Level {
+    int width = 0, height = 0, block = 0, search = 0, range = 0;
+    uint8_t *img1 = nullptr, *img2 = nullptr;     // padded planes, pitch == width
+    mv_t *grid[2] = {nullptr, nullptr};           // MV grids (capacity (H/2)*(W/2))
+    int cur = 0;                                  // which grid holds the current field
+    int cur_block = 0;                            // its block size (0 = nothing yet)
+    uint32_t *spiral = nullptr;                   // rank -> packed (dx, dy)
+    int ncand = 0;
+    int pitch_dw = 0;
+    size_t lds_bytes = 0;
+};
+
+}  // namespace
+
+struct bbme_ctx {
+    bbme_params params{};
+    Geometry geom{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::vector<Level> lv;
+    float *flow = nullptr;                        // dense padded H0 x W0 float2
+    uint32_t *list[2] = {nullptr, nullptr};
+    uint32_t *bits[2] = {nullptr, nullptr};
+    uint32_t *counters = nullptr;                 // 8 words
+    uint8_t *raw[2] = {nullptr, nullptr};         // unpadded frames for bbme_set_frames_device staging
+    bool frames_set = false;
+    int fix_passes = 1;                           // global work-list passes before the tail kernel
+    bool use_graph = true;
+    hipGraphExec_t graph_exec = nullptr;
+    bool profiling = false;
+    float t_total = 0, t_search = 0, t_reg = 0, t_expand = 0, t_search0 = 0;
+    std::vector<uint8_t> host_a, host_b;          // staging for bbme_set_frames_host
+};
+
+namespace {
+
+int check_ctx(const bbme_ctx *c)
+{
+    if (!c) return bbme::fail(BBME_ERR_INVALID, "ctx is null");
+    return BBME_OK;
+}
+
+int check_level(const bbme_ctx *c, int level)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (level < 0 || level >= (int)c->lv.size())
+        return bbme::fail(BBME_ERR_INVALID, "level %d out of range 0..%d", level, (int)c->lv.size() - 1);
+    return BBME_OK;
+}
+
+void drop_graph(bbme_ctx *c)
+{
+    if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+}
+
+// ---- launches ---------------------------------------------------------------------------
+
+template <int B>
+void launch_search_t(const SearchArgs &a, int nblocks, size_t lds, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_search_generic<B>, dim3(nblocks), dim3(64), lds, s, a);
+}
+
+int launch_search(bbme_ctx *c, int level)
+{
+    Level &L = c->lv[level];
+    SearchArgs a{};
+    a.image1 = L.img1; a.image2 = L.img2;
+    a.width = L.width; a.height = L.height;
+    a.range = L.range; a.ncand = L.ncand; a.spiral = L.spiral;
+    if (level + 1 < (int)c->lv.size()) {
+        Level &C = c->lv[level + 1];
+        if (C.cur_block != 2)
+            return bbme::fail(BBME_ERR_STATE, "level %d has not been regularised down to 2x2 blocks", level + 1);
+        a.coarse = C.grid[C.cur];
+        a.coarse_cols = C.width / 2;
+        a.coarse_block = C.block;
+    }
+    L.cur = 0; L.cur_block = L.block;
+    a.out = L.grid[0];
+    a.cols = L.width / L.block;
+    a.pitch_dw = L.pitch_dw;
+    const int nblocks = (L.width / L.block) * (L.height / L.block);
+    switch (L.block) {
+    case 4:  launch_search_t<4>(a, nblocks, L.lds_bytes, c->stream); break;
+    case 8:  launch_search_t<8>(a, nblocks, L.lds_bytes, c->stream); break;
+    case 16: launch_search_t<16>(a, nblocks, L.lds_bytes, c->stream); break;
+    case 32: launch_search_t<32>(a, nblocks, L.lds_bytes, c->stream); break;
+    case 64: launch_search_t<64>(a, nblocks, L.lds_bytes, c->stream); break;
+    default: return bbme::fail(BBME_ERR_UNSUPPORTED, "block size %d", L.block);
+    }
+    HIP_TRY(hipGetLastError());
+    return BBME_OK;
+}
+
+template <int BS>
+void launch_sweep_t(const RegArgs &a0, int fix_passes, hipStream_t s)
+{
+    constexpr int LPB = RegCfg<BS>::LPB;
+    RegArgs a = a0;
+    const long long threads = (long long)a.rows * a.cols * LPB;
+    const int grid = (int)((threads + 255) / 256);
+    hipLaunchKernelGGL(k_reg_pass1<BS>, dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_reg_pass2<BS>, dim3(grid), dim3(256), 0, s, a);
+    int p = 3;
+    for (int f = 0; f < fix_passes; ++f, ++p) {
+        a.pass = p;
+        hipLaunchKernelGGL(k_reg_fix<BS>, dim3(std::min(grid, 128)), dim3(256), 0, s, a);
+    }
+    a.pass = p;
+    hipLaunchKernelGGL(k_reg_tail<BS>, dim3(1), dim3(1024), 0, s, a);
+}
+
+// One regularize_MVs() sweep at block size b (divide_blocks fused when the grid is at 2b).
+int launch_sweep(bbme_ctx *c, int level, int b, int mult)
+{
+    Level &L = c->lv[level];
+    if (mult < 1) return bbme::fail(BBME_ERR_INVALID, "lambda multiplier %d", mult);
+    if (b < 2 || b > L.block || (b & (b - 1)))
+        return bbme::fail(BBME_ERR_INVALID, "block %d is not a power of two in 2..%d", b, L.block);
+    RegArgs a{};
+    if (L.cur_block == b) a.old_shift = 0;
+    else if (L.cur_block == 2 * b) a.old_shift = 1;
+    else return bbme::fail(BBME_ERR_STATE, "level %d grid is at block size %d, cannot sweep at %d",
+                           level, L.cur_block, b);
+    a.image1 = L.img1; a.image2 = L.img2;
+    a.width = L.width; a.height = L.height;
+    a.rows = L.height / b; a.cols = L.width / b;
+    a.old_grid = L.grid[L.cur];
+    a.old_cols = a.cols >> a.old_shift;
+    a.est = L.grid[L.cur ^ 1];
+    // lambda = (float)(B/2), doubled at every halving (motion_framework.cpp:73,95,151); times
+    // (float)lambda_multiplier as at :607
+    float lambda = (float)(L.block / 2);
+    for (int s = L.block; s > b; s >>= 1) lambda = lambda * 2;
+    a.lambda_mult = lambda * (float)mult;
+    a.list0 = c->list[0]; a.list1 = c->list[1];
+    a.bits0 = c->bits[0]; a.bits1 = c->bits[1];
+    a.counters = c->counters;
+    switch (b) {
+    case 2:  launch_sweep_t<2>(a, c->fix_passes, c->stream); break;
+    case 4:  launch_sweep_t<4>(a, c->fix_passes, c->stream); break;
+    case 8:  launch_sweep_t<8>(a, c->fix_passes, c->stream); break;
+    case 16: launch_sweep_t<16>(a, c->fix_passes, c->stream); break;
+    case 32: launch_sweep_t<32>(a, c->fix_passes, c->stream); break;
+    case 64: launch_sweep_t<64>(a, c->fix_passes, c->stream); break;
+    default: return bbme::fail(BBME_ERR_UNSUPPORTED, "block size %d", b);
+    }
+    HIP_TRY(hipGetLastError());
+    L.cur ^= 1;
+    L.cur_block = b;
+    return BBME_OK;
+}
+
+int launch_expand(bbme_ctx *c)
+{
+    Level &L = c->lv[0];
+    if (L.cur_block != 2) return bbme::fail(BBME_ERR_STATE, "level 0 has not been regularised down to 2x2 blocks");
+    const int cc = L.width / 2, cr = L.height / 2;
+    const long long threads = (long long)cc * cr * 2;
+    hipLaunchKernelGGL(k_expand, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream,
+                       L.grid[L.cur], cc, cr, c->flow, L.width);
+    HIP_TRY(hipGetLastError());
+    return BBME_OK;
+}
+
+// The level loop of MF::calcMotionBlockMatching (:115-206)
+int enqueue_pyramid(bbme_ctx *c, hipEvent_t *ev /* optional: 2 + 3*levels + ... */)
+{
+    (void)ev;
+    for (int l = (int)c->lv.size() - 1; l >= 0; --l) {
+        if (int rc = launch_search(c, l)) return rc;
+        for (int b = c->lv[l].block; b > 1; b >>= 1)              // while (block_size > 1) :141
+            for (int mult = 1; mult <= 2; ++mult)                  // lambda_multiplier = l + 1 :145
+                if (int rc = launch_sweep(c, l, b, mult)) return rc;
+    }
+    return launch_expand(c);
+}
+
+int profiled_pyramid(bbme_ctx *c)
+{
+    // eager launches with events between sections (rank-0 diagnostics; not the timed bench path)
+    std::vector<hipEvent_t> ev;
+    auto mark = [&]() -> int {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipEventRecord(e, c->stream));
+        ev.push_back(e);
+        return BBME_OK;
+    };
+    std::vector<int> kind;   // 0 search, 1 reg, 2 expand ; section i lies between ev[i] and ev[i+1]
+    std::vector<int> lvl;
+    if (int rc = mark()) return rc;
+    for (int l = (int)c->lv.size() - 1; l >= 0; --l) {
+        if (int rc = launch_search(c, l)) return rc;
+        if (int rc = mark()) return rc;
+        kind.push_back(0); lvl.push_back(l);
+        for (int b = c->lv[l].block; b > 1; b >>= 1)
+            for (int mult = 1; mult <= 2; ++mult)
+                if (int rc = launch_sweep(c, l, b, mult)) return rc;
+        if (int rc = mark()) return rc;
+        kind.push_back(1); lvl.push_back(l);
+    }
+    if (int rc = launch_expand(c)) return rc;
+    if (int rc = mark()) return rc;
+    kind.push_back(2); lvl.push_back(0);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->t_search = c->t_reg = c->t_expand = c->t_search0 = 0;
+    for (size_t i = 0; i < kind.size(); ++i) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+        if (kind[i] == 0) { c->t_search += ms; if (lvl[i] == 0) c->t_search0 = ms; }
+        else if (kind[i] == 1) c->t_reg += ms;
+        else c->t_expand += ms;
+    }
+    HIP_TRY(hipEventElapsedTime(&c->t_total, ev.front(), ev.back()));
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    return BBME_OK;
+}
+
+}  // namespace
+
+// =========================================================================================
+// C-ABI
+// =========================================================================================
+extern "C" {
+
+int bbme_create(const bbme_params *params, int width, int height, int device, bbme_ctx **out)
+{
+    if (!params || !out) return bbme::fail(BBME_ERR_INVALID, "bbme_create: null argument");
+    *out = nullptr;
+    if (int rc = validate_params(*params)) return rc;
+    Geometry g;
+    if (int rc = plan_padding(width, height, *params, g)) return rc;
+    const int nl = params->num_levels;
+    // grids with fewer than two blocks in a dimension make regularize_MVs read outside the
+    // flow field in the reference (motion_framework.cpp:452-522): undefined there, refused here
+    for (int l = 0; l < nl; ++l) {
+        const int w = g.padded_width >> l, h = g.padded_height >> l, b = params->block_size[l];
+        if (w / b < 2 || h / b < 2)
+            return bbme::fail(BBME_ERR_DEGENERATE,
+                              "level %d is %dx%d with %dx%d blocks: fewer than two blocks in a dimension "
+                              "is undefined behaviour in the reference", l, w, h, b, b);
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return bbme::fail(BBME_ERR_HIP, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return bbme::fail(BBME_ERR_INVALID, "device %d of %d", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+
+    bbme_ctx *c = new bbme_ctx();
+    c->params = *params; c->geom = g; c->device = device;
+    if (const char *e = getenv("BBME_FIX_PASSES")) c->fix_passes = std::max(0, std::min(16, atoi(e)));
+    if (const char *e = getenv("BBME_NO_GRAPH")) c->use_graph = atoi(e) == 0;
+    c->lv.resize(nl);
+    auto cleanup_fail = [&](int rc) { bbme_destroy(c); return rc; };
+    hipError_t err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (err != hipSuccess) return cleanup_fail(bbme::fail(BBME_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(err)));
+    c->own_stream = true;
+    size_t max_blocks = 0;
+    for (int l = 0; l < nl; ++l) {
+        Level &L = c->lv[l];
+        L.width = g.padded_width >> l; L.height = g.padded_height >> l;
+        L.block = params->block_size[l]; L.search = params->search_size[l];
+        SpiralTable sp = build_spiral(L.search, L.block);
+        L.range = sp.range; L.ncand = (int)sp.dx.size();
+        L.pitch_dw = (L.block + 2 * L.range) / 4 + 2;
+        L.lds_bytes = ((size_t)(L.block + 2 * L.range) * L.pitch_dw + (size_t)L.block * L.block / 4) * 4;
+        const size_t plane = (size_t)L.width * L.height + 64;          // slack: row_sad may touch 3 bytes past the end
+        const size_t cells = (size_t)(L.width / 2) * (L.height / 2);
+        max_blocks = std::max(max_blocks, cells);
+        std::vector<uint32_t> packed(sp.dx.size());
+        for (size_t i = 0; i < sp.dx.size(); ++i)
+            packed[i] = ((uint32_t)(uint16_t)sp.dx[i]) | ((uint32_t)(uint16_t)sp.dy[i] << 16);
+        if ((err = hipMalloc(&L.img1, plane)) != hipSuccess || (err = hipMalloc(&L.img2, plane)) != hipSuccess ||
+            (err = hipMalloc(&L.grid[0], cells * sizeof(mv_t))) != hipSuccess ||
+            (err = hipMalloc(&L.grid[1], cells * sizeof(mv_t))) != hipSuccess ||
+            (err = hipMalloc(&L.spiral, packed.size() * 4)) != hipSuccess ||
+            (err = hipMemset(L.img1, 0, plane)) != hipSuccess || (err = hipMemset(L.img2, 0, plane)) != hipSuccess ||
+            (err = hipMemcpy(L.spiral, packed.data(), packed.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
+            return cleanup_fail(bbme::fail(BBME_ERR_HIP, "allocating level %d: %s", l, hipGetErrorString(err)));
+    }
+    const size_t bit_words = (max_blocks + 31) / 32 + 4;
+    const size_t flow_bytes = (size_t)g.padded_width * g.padded_height * 2 * sizeof(float);
+    const size_t raw_bytes = (size_t)width * height + 64;
+    if ((err = hipMalloc(&c->flow, flow_bytes)) != hipSuccess ||
+        (err = hipMalloc(&c->list[0], max_blocks * 4)) != hipSuccess ||
+        (err = hipMalloc(&c->list[1], max_blocks * 4)) != hipSuccess ||
+        (err = hipMalloc(&c->bits[0], bit_words * 4)) != hipSuccess ||
+        (err = hipMalloc(&c->bits[1], bit_words * 4)) != hipSuccess ||
+        (err = hipMalloc(&c->counters, 64)) != hipSuccess ||
+        (err = hipMalloc(&c->raw[0], raw_bytes)) != hipSuccess ||
+        (err = hipMalloc(&c->raw[1], raw_bytes)) != hipSuccess ||
+        (err = hipMemset(c->bits[0], 0, bit_words * 4)) != hipSuccess ||
+        (err = hipMemset(c->bits[1], 0, bit_words * 4)) != hipSuccess ||
+        (err = hipMemset(c->counters, 0, 64)) != hipSuccess ||
+        (err = hipMemset(c->flow, 0, flow_bytes)) != hipSuccess)
+        return cleanup_fail(bbme::fail(BBME_ERR_HIP, "allocating work buffers: %s", hipGetErrorString(err)));
+    HIP_TRY(hipDeviceSynchronize());
+    bbme::clear_error();
+    *out = c;
+    return BBME_OK;
+}
+
+int bbme_destroy(bbme_ctx *c)
+{
+    if (!c) return BBME_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    drop_graph(c);
+    for (Level &L : c->lv) {
+        (void)hipFree(L.img1); (void)hipFree(L.img2);
+        (void)hipFree(L.grid[0]); (void)hipFree(L.grid[1]); (void)hipFree(L.spiral);
+    }
+    (void)hipFree(c->flow);
+    (void)hipFree(c->list[0]); (void)hipFree(c->list[1]);
+    (void)hipFree(c->bits[0]); (void)hipFree(c->bits[1]);
+    (void)hipFree(c->counters);
+    (void)hipFree(c->raw[0]); (void)hipFree(c->raw[1]);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return BBME_OK;
+}
+
+int bbme_set_stream(bbme_ctx *c, void *hip_stream)
+{
+    if (int rc = check_ctx(c)) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    drop_graph(c);
+    if (c->own_stream) { (void)hipStreamDestroy(c->stream); c->own_stream = false; }
+    c->stream = (hipStream_t)hip_stream;
+    if (!c->stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    return BBME_OK;
+}
+
+int bbme_get_geometry(const bbme_ctx *c, int *pw, int *ph, int *px, int *py)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (pw) *pw = c->geom.padded_width;
+    if (ph) *ph = c->geom.padded_height;
+    if (px) *px = c->geom.pad_x;
+    if (py) *py = c->geom.pad_y;
+    return BBME_OK;
+}
+
+int bbme_level_geometry(const bbme_ctx *c, int level, int *w, int *h, int *b, int *s)
+{
+    if (int rc = check_level(c, level)) return rc;
+    const Level &L = c->lv[level];
+    if (w) *w = L.width;
+    if (h) *h = L.height;
+    if (b) *b = L.block;
+    if (s) *s = L.search;
+    return BBME_OK;
+}
+
+int bbme_set_frames_host(bbme_ctx *c, const uint8_t *image1, const uint8_t *image2, int pitch)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (!image1 || !image2 || pitch < c->geom.width) return bbme::fail(BBME_ERR_INVALID, "bbme_set_frames_host: bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    const Geometry &g = c->geom;
+    const uint8_t *src[2] = {image1, image2};
+    for (int which = 0; which < 2; ++which) {
+        c->host_a.resize((size_t)g.padded_width * g.padded_height);
+        pad_zero(src[which], g.width, g.height, pitch, g.pad_x, g.pad_y, c->host_a.data());
+        for (size_t l = 0; l < c->lv.size(); ++l) {
+            Level &L = c->lv[l];
+            uint8_t *dst = which ? L.img2 : L.img1;
+            HIP_TRY(hipMemcpyAsync(dst, c->host_a.data(), (size_t)L.width * L.height, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (l + 1 < c->lv.size()) {
+                c->host_b.resize((size_t)(L.width / 2) * (L.height / 2));
+                pyr_down(c->host_a.data(), L.width, L.height, c->host_b.data());
+                c->host_a.swap(c->host_b);
+            }
+        }
+    }
+    c->frames_set = true;
+    return BBME_OK;
+}
+
+int bbme_set_frames_device(bbme_ctx *c, const uint8_t *d_image1, const uint8_t *d_image2, int pitch)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (!d_image1 || !d_image2 || pitch < c->geom.width) return bbme::fail(BBME_ERR_INVALID, "bbme_set_frames_device: bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    const Geometry &g = c->geom;
+    const uint8_t *src[2] = {d_image1, d_image2};
+    for (int which = 0; which < 2; ++which) {
+        Level &L0 = c->lv[0];
+        uint8_t *p0 = which ? L0.img2 : L0.img1;
+        const long long dws = (long long)(L0.width / 4) * L0.height;
+        hipLaunchKernelGGL(k_pad_zero, dim3((unsigned)((dws + 255) / 256)), dim3(256), 0, c->stream,
+                           src[which], g.width, g.height, pitch, g.pad_x, g.pad_y, p0, L0.width, L0.height);
+        for (size_t l = 1; l < c->lv.size(); ++l) {
+            Level &P = c->lv[l - 1], &L = c->lv[l];
+            const long long px = (long long)L.width * L.height;
+            hipLaunchKernelGGL(k_pyr_down, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, c->stream,
+                               which ? P.img2 : P.img1, P.width, P.height, which ? L.img2 : L.img1);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    c->frames_set = true;
+    return BBME_OK;
+}
+
+int bbme_level_planes_device(bbme_ctx *c, int level, uint8_t **d1, uint8_t **d2)
+{
+    if (int rc = check_level(c, level)) return rc;
+    if (d1) *d1 = c->lv[level].img1;
+    if (d2) *d2 = c->lv[level].img2;
+    c->frames_set = true;          // the caller fills them in place
+    return BBME_OK;
+}
+
+int bbme_set_level_planes_host(bbme_ctx *c, int level, const uint8_t *image1, const uint8_t *image2)
+{
+    if (int rc = check_level(c, level)) return rc;
+    if (!image1 || !image2) return bbme::fail(BBME_ERR_INVALID, "null plane");
+    HIP_TRY(hipSetDevice(c->device));
+    Level &L = c->lv[level];
+    HIP_TRY(hipMemcpyAsync(L.img1, image1, (size_t)L.width * L.height, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(L.img2, image2, (size_t)L.width * L.height, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->frames_set = true;
+    return BBME_OK;
+}
+
+int bbme_get_level_planes_host(bbme_ctx *c, int level, uint8_t *image1, uint8_t *image2)
+{
+    if (int rc = check_level(c, level)) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    Level &L = c->lv[level];
+    if (image1) HIP_TRY(hipMemcpyAsync(image1, L.img1, (size_t)L.width * L.height, hipMemcpyDeviceToHost, c->stream));
+    if (image2) HIP_TRY(hipMemcpyAsync(image2, L.img2, (size_t)L.width * L.height, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BBME_OK;
+}
+
+int bbme_estimate(bbme_ctx *c)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (!c->frames_set) return bbme::fail(BBME_ERR_STATE, "bbme_estimate: no frames set");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->profiling) return profiled_pyramid(c);
+    if (!c->use_graph) return enqueue_pyramid(c, nullptr);
+    if (!c->graph_exec) {
+        // the launch sequence is fixed (no host decisions inside), so capture it once
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        int rc = enqueue_pyramid(c, nullptr);
+        hipError_t e = hipStreamEndCapture(c->stream, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess) return bbme::fail(BBME_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        e = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { c->graph_exec = nullptr; return bbme::fail(BBME_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+    } else {
+        // keep the host-side grid bookkeeping in step with what the graph replays: two sweeps
+        // per block size leave every level's field in grid[0], at 2x2 cells
+        for (Level &L : c->lv) { L.cur = 0; L.cur_block = 2; }
+    }
+    HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
+    return BBME_OK;
+}
+
+int bbme_synchronize(bbme_ctx *c)
+{
+    if (int rc = check_ctx(c)) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BBME_OK;
+}
+
+int bbme_flow_device(bbme_ctx *c, const float **d_flow)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (!d_flow) return bbme::fail(BBME_ERR_INVALID, "null output");
+    *d_flow = c->flow;
+    return BBME_OK;
+}
+
+int bbme_get_flow_host(bbme_ctx *c, float *flow)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (!flow) return bbme::fail(BBME_ERR_INVALID, "null output");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = (size_t)c->geom.padded_width * c->geom.padded_height * 2 * sizeof(float);
+    HIP_TRY(hipMemcpyAsync(flow, c->flow, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BBME_OK;
+}
+
+int bbme_get_cells_host(bbme_ctx *c, int16_t *cells)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (!cells) return bbme::fail(BBME_ERR_INVALID, "null output");
+    Level &L = c->lv[0];
+    if (L.cur_block != 2) return bbme::fail(BBME_ERR_STATE, "level 0 is not at 2x2 cells");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = (size_t)(L.width / 2) * (L.height / 2);
+    HIP_TRY(hipMemcpyAsync(cells, L.grid[L.cur], n * sizeof(mv_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BBME_OK;
+}
+
+int bbme_stage_search(bbme_ctx *c, int level)
+{
+    if (int rc = check_level(c, level)) return rc;
+    if (!c->frames_set) return bbme::fail(BBME_ERR_STATE, "no frames set");
+    HIP_TRY(hipSetDevice(c->device));
+    return launch_search(c, level);
+}
+
+int bbme_stage_regularize(bbme_ctx *c, int level, int block, int mult)
+{
+    if (int rc = check_level(c, level)) return rc;
+    if (!c->frames_set) return bbme::fail(BBME_ERR_STATE, "no frames set");
+    HIP_TRY(hipSetDevice(c->device));
+    return launch_sweep(c, level, block, mult);
+}
+
+int bbme_stage_get_mvs(bbme_ctx *c, int level, int block, int16_t *mvs)
+{
+    if (int rc = check_level(c, level)) return rc;
+    Level &L = c->lv[level];
+    if (!mvs) return bbme::fail(BBME_ERR_INVALID, "null output");
+    if (L.cur_block == 0) return bbme::fail(BBME_ERR_STATE, "level %d has no MV grid yet", level);
+    if (block < 1 || block > L.cur_block || (L.cur_block % block))
+        return bbme::fail(BBME_ERR_INVALID, "block %d does not divide the grid's block size %d", block, L.cur_block);
+    HIP_TRY(hipSetDevice(c->device));
+    const int rows = L.height / L.cur_block, cols = L.width / L.cur_block;
+    std::vector<mv_t> host((size_t)rows * cols);
+    HIP_TRY(hipMemcpyAsync(host.data(), L.grid[L.cur], host.size() * sizeof(mv_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // divide_blocks (:845-862) repeated: every finer block inherits its parent's MV
+    const int f = L.cur_block / block, orows = rows * f, ocols = cols * f;
+    for (int r = 0; r < orows; ++r)
+        for (int q = 0; q < ocols; ++q) {
+            const mv_t m = host[(size_t)(r / f) * cols + q / f];
+            mvs[2 * ((size_t)r * ocols + q)] = (int16_t)(m & 0xffffu);
+            mvs[2 * ((size_t)r * ocols + q) + 1] = (int16_t)(m >> 16);
+        }
+    return BBME_OK;
+}
+
+int bbme_stage_set_mvs(bbme_ctx *c, int level, int block, const int16_t *mvs)
+{
+    if (int rc = check_level(c, level)) return rc;
+    Level &L = c->lv[level];
+    if (!mvs) return bbme::fail(BBME_ERR_INVALID, "null input");
+    if (block < 2 || block > L.block || (block & (block - 1)))
+        return bbme::fail(BBME_ERR_INVALID, "block %d is not a power of two in 2..%d", block, L.block);
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = (size_t)(L.height / block) * (L.width / block);
+    std::vector<mv_t> host(n);
+    for (size_t i = 0; i < n; ++i) host[i] = ((uint32_t)(uint16_t)mvs[2 * i]) | ((uint32_t)(uint16_t)mvs[2 * i + 1] << 16);
+    L.cur = 0; L.cur_block = block;
+    HIP_TRY(hipMemcpyAsync(L.grid[0], host.data(), n * sizeof(mv_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BBME_OK;
+}
+
+int bbme_stage_expand(bbme_ctx *c)
+{
+    if (int rc = check_ctx(c)) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    return launch_expand(c);
+}
+
+int bbme_last_sweep_passes(bbme_ctx *c, int *passes)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (!passes) return bbme::fail(BBME_ERR_INVALID, "null output");
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t host[8];
+    HIP_TRY(hipMemcpyAsync(host, c->counters, sizeof host, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    passes[0] = (int)host[3];
+    passes[1] = (int)host[4];
+    if (host[5]) return bbme::fail(BBME_ERR_STATE, "a regulariser sweep hit its pass cap without converging");
+    return BBME_OK;
+}
+
+int bbme_set_profiling(bbme_ctx *c, int enabled)
+{
+    if (int rc = check_ctx(c)) return rc;
+    c->profiling = enabled != 0;
+    return BBME_OK;
+}
+
+int bbme_get_timings(bbme_ctx *c, float *total, float *search, float *reg, float *expand, float *search0)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (total) *total = c->t_total;
+    if (search) *search = c->t_search;
+    if (reg) *reg = c->t_reg;
+    if (expand) *expand = c->t_expand;
+    if (search0) *search0 = c->t_search0;
+    return BBME_OK;
+}
+
+int bbme_selftest_isa(int device, int *mismatches)
+{
+    if (!mismatches) return bbme::fail(BBME_ERR_INVALID, "null output");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return bbme::fail(BBME_ERR_HIP, "no HIP device %d", device);
+    HIP_TRY(hipSetDevice(device));
+    const int n = 1 << 16;
+    std::vector<uint32_t> a(n), b(n), cc(n), sad(n), al(n), s16(n);
+    std::vector<unsigned long long> qs(n);
+    uint32_t x = 0x12345678u;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 17; x ^= x << 5; return x; };
+    for (int i = 0; i < n; ++i) { a[i] = rnd(); b[i] = rnd(); cc[i] = rnd(); }
+    uint32_t *da, *db, *dc, *dsad, *dal, *ds16; unsigned long long *dqs;
+    HIP_TRY(hipMalloc(&da, n * 4)); HIP_TRY(hipMalloc(&db, n * 4)); HIP_TRY(hipMalloc(&dc, n * 4));
+    HIP_TRY(hipMalloc(&dsad, n * 4)); HIP_TRY(hipMalloc(&dal, n * 4)); HIP_TRY(hipMalloc(&ds16, n * 4));
+    HIP_TRY(hipMalloc(&dqs, n * 8));
+    HIP_TRY(hipMemcpy(da, a.data(), n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db, b.data(), n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dc, cc.data(), n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_probe_sad, dim3(n / 256), dim3(256), 0, 0, da, db, dc, dsad, dqs, dal, ds16, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(sad.data(), dsad, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(al.data(), dal, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(s16.data(), ds16, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(qs.data(), dqs, n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc); (void)hipFree(dsad); (void)hipFree(dal);
+    (void)hipFree(ds16); (void)hipFree(dqs);
+    auto absd = [](int p, int q) { return p > q ? p - q : q - p; };
+    mismatches[0] = mismatches[1] = mismatches[2] = mismatches[3] = 0;
+    for (int i = 0; i < n; ++i) {
+        uint32_t e = cc[i];
+        for (int k = 0; k < 4; ++k) e += absd((a[i] >> (8 * k)) & 255, (b[i] >> (8 * k)) & 255);
+        if (e != sad[i]) ++mismatches[0];
+        const unsigned long long w = ((unsigned long long)b[i] << 32) | a[i];
+        if ((uint32_t)(w >> (8 * (cc[i] & 3))) != al[i]) ++mismatches[1];
+        // v_qsad_pk_u16_u8: four SADs of src1's 4 bytes against src0 shifted by 0..3 bytes,
+        // each added to the matching 16-bit lane of the accumulator
+        const uint32_t ref = cc[i] ^ a[i];
+        const unsigned long long acc = ((unsigned long long)(cc[i] & 0x00ff00ffu) << 32) | (cc[i] & 0x0f0f0f0fu);
+        unsigned long long eq = 0;
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t win = (uint32_t)(w >> (8 * k));
+            uint32_t s = (uint32_t)((acc >> (16 * k)) & 0xffff);
+            for (int q = 0; q < 4; ++q) s += absd((win >> (8 * q)) & 255, (ref >> (8 * q)) & 255);
+            eq |= (unsigned long long)(s & 0xffff) << (16 * k);
+        }
+        if (eq != qs[i]) ++mismatches[2];
+        const uint32_t e16 = (cc[i] & 0xffffu) + absd(a[i] & 0xffff, b[i] & 0xffff) + absd(a[i] >> 16, b[i] >> 16);
+        if (e16 != s16[i]) ++mismatches[3];
+    }
+    return BBME_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,375 @@
+// bbme_host.cpp -- host side of libbbme.so: everything of the drop-in boundary that the
+// reference also does on the CPU.  MF::MF's padding + pyramid (motion_framework.cpp:4-111),
+// the spiral visiting order (:326-411) as a table, and the Flow class' .flo codec and EPE
+// (rw_flow.cpp:39-200,309-332).  No GPU code here; no dependency on oracle/.
+#include "bbme_internal.hpp"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+
+namespace bbme {
+
+// ---------------------------------------------------------------------------------------
+// error channel
+// ---------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+int fail(int status, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return status;
+}
+
+void clear_error() { g_last_error.clear(); }
+
+static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+int validate_params(const bbme_params &p)
+{
+    if (p.num_levels <= 0 || p.num_levels > BBME_MAX_LEVELS)      // assert(num_levels > 0), :7
+        return fail(BBME_ERR_INVALID, "num_levels must be in 1..%d (got %d)", BBME_MAX_LEVELS, p.num_levels);
+    for (int i = 0; i < p.num_levels; ++i) {
+        if (!is_pow2(p.block_size[i]) || p.block_size[i] < 4 || p.block_size[i] > 64)
+            return fail(BBME_ERR_UNSUPPORTED,
+                        "block_size[%d]=%d: the kernels need a power of two in 4..64 "
+                        "(the regulariser halves blocks down to 2x2)", i, p.block_size[i]);
+        if (p.search_size[i] <= 0)
+            return fail(BBME_ERR_INVALID, "search_size[%d]=%d must be positive", i, p.search_size[i]);
+        int range = (p.search_size[i] - p.block_size[i]) >> 1;
+        if (range > 63)
+            return fail(BBME_ERR_UNSUPPORTED, "search range %d at level %d exceeds 63", range, i);
+    }
+    return BBME_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Padding search (motion_framework.cpp:14-54).  The reference grows height and width one
+// pixel at a time until both are divisible by 2^i * block_size[i] for every level, and
+// gives up when either reaches twice the original.  Each dimension therefore ends at the
+// next multiple of M = lcm_i(2^i * block_size[i]); reaching 2x the original is an error.
+// ---------------------------------------------------------------------------------------
+int plan_padding(int width, int height, const bbme_params &p, Geometry &g)
+{
+    if (width <= 0 || height <= 0)
+        return fail(BBME_ERR_INVALID, "frame size %dx%d is not positive", width, height);
+    long long m = 1;
+    for (int i = 0; i < p.num_levels; ++i)
+        m = std::lcm(m, (long long)p.block_size[i] << i);
+    long long th = ((height + m - 1) / m) * m, tw = ((width + m - 1) / m) * m;
+    if (th >= 2LL * height || tw >= 2LL * width)
+        return fail(BBME_ERR_PADDING,
+                    "Could not find any multiples of the block size that match padded image dimensions "
+                    "(%dx%d, need multiples of %lld)", width, height, m);
+    if ((th - height) % 2 != 0 || (tw - width) % 2 != 0)
+        return fail(BBME_ERR_ODD_PADDING,
+                    "padded size %lldx%lld differs from %dx%d by an odd amount: the reference would "
+                    "allocate a mis-sized image (motion_framework.cpp:50-58)", tw, th, width, height);
+    g.width = width; g.height = height;
+    g.padded_width = (int)tw; g.padded_height = (int)th;
+    g.pad_x = (int)(tw - width) / 2; g.pad_y = (int)(th - height) / 2;
+    return BBME_OK;
+}
+
+void pad_zero(const uint8_t *src, int width, int height, int pitch, int pad_x, int pad_y, uint8_t *dst)
+{
+    const int pw = width + 2 * pad_x;
+    uint8_t *out = dst;
+    for (int y = 0; y < pad_y; ++y, out += pw) memset(out, 0, (size_t)pw);
+    for (int y = 0; y < height; ++y, out += pw) {
+        memset(out, 0, (size_t)pad_x);
+        memcpy(out + pad_x, src + (size_t)y * pitch, (size_t)width);
+        memset(out + pad_x + width, 0, (size_t)pad_x);
+    }
+    for (int y = 0; y < pad_y; ++y, out += pw) memset(out, 0, (size_t)pw);
+}
+
+// cv::pyrDown on 8-bit data (motion_framework.cpp:89-90): 5x5 binomial [1 4 6 4 1]^2 / 256,
+// integer with one rounding (+128 >> 8), BORDER_REFLECT_101, destination pixel (x,y) centred on
+// source (2x,2y).  Horizontal sums of the five source rows of a destination row are kept in a
+// ring so every source row is filtered once.
+static inline int mirror101(int p, int n)
+{
+    if (n == 1) return 0;
+    for (;;) {
+        if (p < 0) p = -p;
+        else if (p >= n) p = 2 * n - 2 - p;
+        else return p;
+    }
+}
+
+void pyr_down(const uint8_t *src, int sw, int sh, uint8_t *dst)
+{
+    const int dw = sw / 2, dh = sh / 2;
+    std::vector<int> hsum((size_t)sh * dw);
+    std::vector<int> xm((size_t)dw * 5);
+    for (int x = 0; x < dw; ++x)
+        for (int t = 0; t < 5; ++t) xm[(size_t)x * 5 + t] = mirror101(2 * x + t - 2, sw);
+    for (int y = 0; y < sh; ++y) {
+        const uint8_t *s = src + (size_t)y * sw;
+        int *h = &hsum[(size_t)y * dw];
+        for (int x = 0; x < dw; ++x) {
+            const int *m = &xm[(size_t)x * 5];
+            h[x] = s[m[0]] + 4 * s[m[1]] + 6 * s[m[2]] + 4 * s[m[3]] + s[m[4]];
+        }
+    }
+    for (int y = 0; y < dh; ++y) {
+        const int *r0 = &hsum[(size_t)mirror101(2 * y - 2, sh) * dw];
+        const int *r1 = &hsum[(size_t)mirror101(2 * y - 1, sh) * dw];
+        const int *r2 = &hsum[(size_t)mirror101(2 * y, sh) * dw];
+        const int *r3 = &hsum[(size_t)mirror101(2 * y + 1, sh) * dw];
+        const int *r4 = &hsum[(size_t)mirror101(2 * y + 2, sh) * dw];
+        uint8_t *d = dst + (size_t)y * dw;
+        for (int x = 0; x < dw; ++x)
+            d[x] = (uint8_t)((r0[x] + 4 * r1[x] + 6 * r2[x] + 4 * r3[x] + r4[x] + 128) >> 8);
+    }
+}
+
+// cv::resize(img, img, Size(), 4, 4, INTER_LINEAR) on 8-bit data (main_class.cpp:32-33):
+// OpenCV's fixed-point bilinear -- 11-bit coefficients, horizontal pass to int, vertical pass
+// ((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2) >> 2.
+void resize_x4(const uint8_t *src, int sw, int sh, uint8_t *dst)
+{
+    const int dw = sw * 4, dh = sh * 4;
+    auto coef = [](float f) {
+        long r = lrintf(f * 2048.f);
+        return (short)(r > 32767 ? 32767 : (r < -32768 ? -32768 : r));
+    };
+    std::vector<int> sx0(dw), sx1(dw);
+    std::vector<short> ax0(dw), ax1(dw);
+    for (int dx = 0; dx < dw; ++dx) {
+        float fx = (float)((dx + 0.5) * 0.25 - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) { sx = 0; fx = 0; }
+        if (sx >= sw - 1) { sx = sw - 1; fx = 0; }
+        sx0[dx] = sx;
+        sx1[dx] = sx + 1 < sw ? sx + 1 : sx;       // weight is 0 there
+        ax0[dx] = coef(1.f - fx);
+        ax1[dx] = coef(fx);
+        if (sx + 1 >= sw) { ax0[dx] = 2048; ax1[dx] = 0; }
+    }
+    std::vector<int> row0(dw), row1(dw);
+    int have0 = -1, have1 = -1;
+    auto hpass = [&](int sy, std::vector<int> &out) {
+        const uint8_t *s = src + (size_t)sy * sw;
+        for (int dx = 0; dx < dw; ++dx) out[dx] = s[sx0[dx]] * ax0[dx] + s[sx1[dx]] * ax1[dx];
+    };
+    for (int dy = 0; dy < dh; ++dy) {
+        float fy = (float)((dy + 0.5) * 0.25 - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        int b0 = coef(1.f - fy), b1 = coef(fy);
+        int y0 = sy < 0 ? 0 : (sy > sh - 1 ? sh - 1 : sy);
+        int y1 = sy + 1 < 0 ? 0 : (sy + 1 > sh - 1 ? sh - 1 : sy + 1);
+        if (have0 != y0) {
+            if (have1 == y0) { row0.swap(row1); std::swap(have0, have1); }
+            else { hpass(y0, row0); have0 = y0; }
+        }
+        if (have1 != y1) { hpass(y1, row1); have1 = y1; }
+        uint8_t *d = dst + (size_t)dy * dw;
+        for (int dx = 0; dx < dw; ++dx)
+            d[dx] = (uint8_t)((((b0 * (row0[dx] >> 4)) >> 16) + ((b1 * (row1[dx] >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Spiral order (motion_framework.cpp:326-411): centre; then for m = 1,3,5,... < shift:
+// right m, down m, left m+1, up m+1; finally right m-1.  Walked literally.
+// ---------------------------------------------------------------------------------------
+SpiralTable build_spiral(int search_size, int block_size)
+{
+    SpiralTable t;
+    const int shift = search_size - block_size;
+    int l = 0, k = 0, m, s;
+    auto emit = [&]() { t.dx.push_back((int16_t)l); t.dy.push_back((int16_t)k); };
+    emit();
+    for (m = 1; m < shift; m += 2) {
+        for (s = 0; s < m; ++s) { ++l; emit(); }
+        for (s = 0; s < m; ++s) { ++k; emit(); }
+        for (s = 0; s < m + 1; ++s) { --l; emit(); }
+        for (s = 0; s < m + 1; ++s) { --k; emit(); }
+    }
+    for (s = 0; s < m - 1; ++s) { ++l; emit(); }
+    int r = 0;
+    for (size_t i = 0; i < t.dx.size(); ++i) {
+        r = std::max(r, std::abs((int)t.dx[i]));
+        r = std::max(r, std::abs((int)t.dy[i]));
+    }
+    t.range = r;
+    t.side = 2 * r + 1;
+    t.rank_pitch = (t.side + 3) & ~3;
+    t.rank_of.assign((size_t)t.rank_pitch * t.side, 0xFFFF);
+    for (size_t i = 0; i < t.dx.size(); ++i)
+        t.rank_of[(size_t)(t.dy[i] + r) * t.rank_pitch + (t.dx[i] + r)] = (uint16_t)i;
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------
+// Flow::ReadFlowFile / WriteFlowFile / CalculateMSE (rw_flow.cpp)
+// ---------------------------------------------------------------------------------------
+static const float kTagFloat = 202021.25f;      // rw_flow.cpp:25
+static const char kTagString[] = "PIEH";        // rw_flow.cpp:26
+
+int flo_read(const char *filename, int *width, int *height, float **data)
+{
+    if (!filename) return fail(BBME_ERR_IO, "ReadFlowFile: empty filename");
+    const char *dot = strrchr(filename, '.');
+    if (!dot || strcmp(dot, ".flo") != 0)
+        return fail(BBME_ERR_IO, "ReadFlowFile extension .flo expected");
+    FILE *f = fopen(filename, "rb");
+    if (!f) return fail(BBME_ERR_IO, "ReadFlowFile: could not open file %s", filename);
+    float tag; int w, h;
+    if (fread(&tag, 4, 1, f) != 1 || fread(&w, 4, 1, f) != 1 || fread(&h, 4, 1, f) != 1) {
+        fclose(f); return fail(BBME_ERR_IO, "ReadFlowFile: problem reading file");
+    }
+    if (tag != kTagFloat) { fclose(f); return fail(BBME_ERR_IO, "ReadFlowFile: wrong tag (possibly due to big-endian machine?)"); }
+    if (w < 1 || w > 99999) { fclose(f); return fail(BBME_ERR_IO, "ReadFlowFile: illegal width %d", w); }
+    if (h < 1 || h > 99999) { fclose(f); return fail(BBME_ERR_IO, "ReadFlowFile: illegal height %d", h); }
+    const size_t n = (size_t)w * h * 2;
+    float *buf = (float *)malloc(n * sizeof(float));
+    if (!buf) { fclose(f); return fail(BBME_ERR_IO, "ReadFlowFile: out of memory"); }
+    if (fread(buf, sizeof(float), n, f) != n) { free(buf); fclose(f); return fail(BBME_ERR_IO, "ReadFlowFile: file is too short"); }
+    if (fgetc(f) != EOF) { free(buf); fclose(f); return fail(BBME_ERR_IO, "ReadFlowFile: file is too long"); }
+    fclose(f);
+    *width = w; *height = h; *data = buf;
+    return BBME_OK;
+}
+
+int flo_write(const char *filename, int width, int height, const float *data)
+{
+    if (!filename) return fail(BBME_ERR_IO, "WriteFlowFile: empty filename");
+    const char *dot = strrchr(filename, '.');
+    if (!dot) return fail(BBME_ERR_IO, "WriteFlowFile: extension required in filename");
+    if (strcmp(dot, ".flo") != 0) return fail(BBME_ERR_IO, "WriteFlowFile: filename should have extension '.flo'");
+    if (width < 1 || height < 1 || !data) return fail(BBME_ERR_INVALID, "WriteFlowFile: empty image");
+    FILE *f = fopen(filename, "wb");
+    if (!f) return fail(BBME_ERR_IO, "WriteFlowFile: could not open file %s", filename);
+    const size_t n = (size_t)width * height * 2;
+    bool ok = fwrite(kTagString, 1, 4, f) == 4 && fwrite(&width, 4, 1, f) == 1 && fwrite(&height, 4, 1, f) == 1;
+    ok = ok && fwrite(data, sizeof(float), n, f) == n;
+    ok = (fclose(f) == 0) && ok;
+    return ok ? BBME_OK : fail(BBME_ERR_IO, "WriteFlowFile: problem writing data");
+}
+
+static inline bool unknown_flow(float u, float v)
+{
+    return std::fabs(u) > 1e9 || std::fabs(v) > 1e9 || std::isnan(u) || std::isnan(v);
+}
+
+double calculate_mse(const float *gtruth, const float *flow, int width, int height)
+{
+    long long count = 0;
+    double error = 0;
+    const size_t n = (size_t)width * height;
+    for (size_t i = 0; i < n; ++i) {
+        const float gu = gtruth[2 * i], gv = gtruth[2 * i + 1];
+        if (unknown_flow(gu, gv)) continue;
+        ++count;
+        const float du = gu - flow[2 * i], dv = gv - flow[2 * i + 1];
+        const float sq = du * du + dv * dv;     // float arithmetic as the reference's expression
+        error += std::sqrt(sq);
+    }
+    return error / (double)count;
+}
+
+void subsample_div4(const float *flow_padded, int padded_width, int padded_height,
+                    int pad_x, int pad_y, float *out, int out_width)
+{
+    for (int i = pad_y; i < padded_height - pad_y; i += 4)
+        for (int j = pad_x; j < padded_width - pad_x; j += 4) {
+            const float *s = flow_padded + 2 * ((size_t)i * padded_width + j);
+            float *d = out + 2 * ((size_t)((i - pad_y) / 4) * out_width + (j - pad_x) / 4);
+            d[0] = s[0] / 4;
+            d[1] = s[1] / 4;
+        }
+}
+
+}  // namespace bbme
+
+// ---------------------------------------------------------------------------------------
+// C-ABI, host-only entry points
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+const char *bbme_version(void) { return "bbme 0.1 (gfx950)"; }
+const char *bbme_last_error(void) { return bbme::g_last_error.c_str(); }
+
+int bbme_plan_padding(int width, int height, const bbme_params *params,
+                      int *padded_width, int *padded_height, int *pad_x, int *pad_y)
+{
+    if (!params) return bbme::fail(BBME_ERR_INVALID, "params is null");
+    if (int rc = bbme::validate_params(*params)) return rc;
+    bbme::Geometry g;
+    if (int rc = bbme::plan_padding(width, height, *params, g)) return rc;
+    if (padded_width) *padded_width = g.padded_width;
+    if (padded_height) *padded_height = g.padded_height;
+    if (pad_x) *pad_x = g.pad_x;
+    if (pad_y) *pad_y = g.pad_y;
+    return BBME_OK;
+}
+
+int bbme_pad_zero_host(const uint8_t *src, int width, int height, int pitch, int pad_x, int pad_y, uint8_t *dst)
+{
+    if (!src || !dst || width <= 0 || height <= 0 || pitch < width || pad_x < 0 || pad_y < 0)
+        return bbme::fail(BBME_ERR_INVALID, "bbme_pad_zero_host: bad arguments");
+    bbme::pad_zero(src, width, height, pitch, pad_x, pad_y, dst);
+    return BBME_OK;
+}
+
+int bbme_pyr_down_host(const uint8_t *src, int sw, int sh, uint8_t *dst)
+{
+    if (!src || !dst || sw < 2 || sh < 2) return bbme::fail(BBME_ERR_INVALID, "bbme_pyr_down_host: bad arguments");
+    bbme::pyr_down(src, sw, sh, dst);
+    return BBME_OK;
+}
+
+int bbme_resize_x4_host(const uint8_t *src, int sw, int sh, uint8_t *dst)
+{
+    if (!src || !dst || sw < 1 || sh < 1) return bbme::fail(BBME_ERR_INVALID, "bbme_resize_x4_host: bad arguments");
+    bbme::resize_x4(src, sw, sh, dst);
+    return BBME_OK;
+}
+
+int bbme_flo_read(const char *filename, int *width, int *height, float **data)
+{
+    if (!width || !height || !data) return bbme::fail(BBME_ERR_INVALID, "bbme_flo_read: null output");
+    return bbme::flo_read(filename, width, height, data);
+}
+
+int bbme_flo_write(const char *filename, int width, int height, const float *data)
+{
+    return bbme::flo_write(filename, width, height, data);
+}
+
+int bbme_calculate_mse(const float *gtruth, const float *flow, int width, int height, double *out)
+{
+    if (!gtruth || !flow || !out || width < 1 || height < 1)
+        return bbme::fail(BBME_ERR_INVALID, "bbme_calculate_mse: bad arguments");
+    *out = bbme::calculate_mse(gtruth, flow, width, height);
+    return BBME_OK;
+}
+
+int bbme_subsample_div4(const float *flow_padded, int padded_width, int padded_height,
+                        int pad_x, int pad_y, float *out, int out_width, int out_height)
+{
+    if (!flow_padded || !out) return bbme::fail(BBME_ERR_INVALID, "bbme_subsample_div4: null pointer");
+    const int need_w = (padded_width - 2 * pad_x + 3) / 4, need_h = (padded_height - 2 * pad_y + 3) / 4;
+    if (out_width < need_w || out_height < need_h)
+        return bbme::fail(BBME_ERR_INVALID, "bbme_subsample_div4: output %dx%d smaller than %dx%d",
+                          out_width, out_height, need_w, need_h);
+    bbme::subsample_div4(flow_padded, padded_width, padded_height, pad_x, pad_y, out, out_width);
+    return BBME_OK;
+}
+
+void bbme_free(void *p) { free(p); }
+
+}  // extern "C"

@@ -1,0 +1,45 @@
+// bbme_internal.hpp -- declarations shared by the host side and the HIP side of libbbme.so.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "bbme.h"
+
+namespace bbme {
+
+// ---- error channel -------------------------------------------------------------------
+int fail(int status, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+void clear_error();
+
+// ---- host prep (MF::MF, motion_framework.cpp:4-111) ----------------------------------
+struct Geometry {
+    int width = 0, height = 0;             // original frame
+    int padded_width = 0, padded_height = 0, pad_x = 0, pad_y = 0;
+};
+int plan_padding(int width, int height, const bbme_params &p, Geometry &g);
+int validate_params(const bbme_params &p);
+void pad_zero(const uint8_t *src, int width, int height, int pitch, int pad_x, int pad_y, uint8_t *dst);
+void pyr_down(const uint8_t *src, int sw, int sh, uint8_t *dst);
+void resize_x4(const uint8_t *src, int sw, int sh, uint8_t *dst);
+
+// ---- spiral order of find_min_block_spiral (motion_framework.cpp:326-411) ------------
+// Built by walking the spiral exactly as the reference loop does.
+struct SpiralTable {
+    int range = 0;                         // R = max(0, (search_size - block_size) >> 1)
+    int side = 0;                          // 2R+1
+    std::vector<int16_t> dx, dy;           // visit order: rank -> (dx, dy)
+    std::vector<uint16_t> rank_of;         // [(dy+R)*rank_pitch + (dx+R)] -> rank
+    int rank_pitch = 0;                    // >= side, multiple of 4 (groups of 4 dx)
+};
+SpiralTable build_spiral(int search_size, int block_size);
+
+// ---- Flow (rw_flow.cpp) ---------------------------------------------------------------
+int flo_read(const char *filename, int *width, int *height, float **data);
+int flo_write(const char *filename, int width, int height, const float *data);
+double calculate_mse(const float *gtruth, const float *flow, int width, int height);
+void subsample_div4(const float *flow_padded, int padded_width, int padded_height,
+                    int pad_x, int pad_y, float *out, int out_width);
+
+}  // namespace bbme

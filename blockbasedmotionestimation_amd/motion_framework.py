@@ -1,0 +1,200 @@
+"""Python mirror of the reference's MF class (motion_framework.h:9-54) over the C-ABI.
+
+    mf = MF(image1, image2, search_size, block_size, num_levels)   # MF::MF, motion_framework.cpp:4-111
+    flow = mf.calcMotionBlockMatching()                             # :113-219 -> (H_pad, W_pad, 2) float32
+    mf.padded_height, mf.padded_width, mf.padding_x, mf.padding_y   # public fields :16-19
+
+Argument meaning and order follow the reference: arrays are indexed [0] = finest level,
+search_size is the window side length.  Errors the reference reports with assert / exit(1)
+raise BbmeError here.  All arithmetic runs in the HIP kernels of libbbme.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+
+class MF:
+    def __init__(self, image1, image2, search_size, block_size, num_levels=None, device=0,
+                 frames_on_device=False):
+        if num_levels is None:
+            num_levels = len(block_size)
+        if num_levels <= 0:
+            raise _capi.BbmeError(_capi.ERR_INVALID, "num_levels must be > 0")       # assert :7
+        search_size = list(search_size)[:num_levels]
+        block_size = list(block_size)[:num_levels]
+        self._ctx = C.c_void_p()
+        self._lib = _capi.lib()
+        self.device = device
+        self._torch_frames = None
+        if frames_on_device:
+            import torch
+            if tuple(image1.shape) != tuple(image2.shape):
+                raise _capi.BbmeError(_capi.ERR_INVALID, "image1.size() != image2.size()")
+            h, w = image1.shape
+        else:
+            image1 = np.ascontiguousarray(image1, dtype=np.uint8)
+            image2 = np.ascontiguousarray(image2, dtype=np.uint8)
+            if image1.ndim != 2 or image1.shape != image2.shape:                        # assert :8
+                raise _capi.BbmeError(_capi.ERR_INVALID, "image1.size() != image2.size()")
+            h, w = image1.shape
+        self.orig_height, self.orig_width = h, w
+        self.params = _capi.make_params(search_size, block_size)
+        _capi.check(self._lib.bbme_create(C.byref(self.params), w, h, device, C.byref(self._ctx)))
+        pw, ph, px, py = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _capi.check(self._lib.bbme_get_geometry(self._ctx, C.byref(pw), C.byref(ph), C.byref(px), C.byref(py)))
+        self.padded_width, self.padded_height = pw.value, ph.value
+        self.padding_x, self.padding_y = px.value, py.value
+        self.num_levels = num_levels
+        if frames_on_device:
+            self.set_frames_device(image1, image2)
+        else:
+            _capi.check(self._lib.bbme_set_frames_host(self._ctx, image1.ctypes.data, image2.ctypes.data, w))
+
+    # -- lifetime -------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.bbme_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- inputs ---------------------------------------------------------------------------
+    def set_frames_device(self, image1, image2):
+        """Frames already in HBM (torch uint8 CUDA tensors, H x W): padding + pyramid on the GPU."""
+        assert image1.is_cuda and image2.is_cuda and image1.dtype.itemsize == 1
+        assert image1.stride(1) == 1 and image2.stride(1) == 1 and image1.stride(0) == image2.stride(0)
+        self._torch_frames = (image1, image2)
+        _capi.check(self._lib.bbme_set_frames_device(self._ctx, image1.data_ptr(), image2.data_ptr(),
+                                                     image1.stride(0)))
+
+    def set_stream(self, hip_stream_handle):
+        _capi.check(self._lib.bbme_set_stream(self._ctx, C.c_void_p(hip_stream_handle)))
+
+    def level_geometry(self, level):
+        w, h, b, s = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _capi.check(self._lib.bbme_level_geometry(self._ctx, level, C.byref(w), C.byref(h), C.byref(b), C.byref(s)))
+        return w.value, h.value, b.value, s.value
+
+    def set_level_planes(self, level, image1, image2):
+        w, h, _, _ = self.level_geometry(level)
+        image1 = np.ascontiguousarray(image1, np.uint8)
+        image2 = np.ascontiguousarray(image2, np.uint8)
+        assert image1.shape == (h, w) and image2.shape == (h, w)
+        _capi.check(self._lib.bbme_set_level_planes_host(self._ctx, level, image1.ctypes.data, image2.ctypes.data))
+
+    def get_level_planes(self, level):
+        w, h, _, _ = self.level_geometry(level)
+        a = np.empty((h, w), np.uint8)
+        b = np.empty((h, w), np.uint8)
+        _capi.check(self._lib.bbme_get_level_planes_host(self._ctx, level, a.ctypes.data, b.ctypes.data))
+        return a, b
+
+    # -- the hot path ---------------------------------------------------------------------
+    def estimate_async(self):
+        """Enqueue MF::calcMotionBlockMatching on the context's stream; no host wait."""
+        _capi.check(self._lib.bbme_estimate(self._ctx))
+
+    def synchronize(self):
+        _capi.check(self._lib.bbme_synchronize(self._ctx))
+
+    def get_flow(self):
+        out = np.empty((self.padded_height, self.padded_width, 2), np.float32)
+        _capi.check(self._lib.bbme_get_flow_host(self._ctx, out.ctypes.data))
+        return out
+
+    def get_cells(self):
+        out = np.empty((self.padded_height // 2, self.padded_width // 2, 2), np.int16)
+        _capi.check(self._lib.bbme_get_cells_host(self._ctx, out.ctypes.data))
+        return out
+
+    def flow_device_ptr(self):
+        p = C.c_void_p()
+        _capi.check(self._lib.bbme_flow_device(self._ctx, C.byref(p)))
+        return p.value
+
+    def calcMotionBlockMatching(self):
+        """cv::Mat MF::calcMotionBlockMatching() -- dense padded (H, W, 2) float32 (u, v) field."""
+        self.estimate_async()
+        return self.get_flow()
+
+    # -- the reference's private methods, one stage at a time (parity tests) --------------
+    def stage_search(self, level):
+        """copyMVs() + calcLevelBM() of one level."""
+        _capi.check(self._lib.bbme_stage_search(self._ctx, level))
+
+    def stage_regularize(self, level, block, lambda_multiplier):
+        """One regularize_MVs() sweep (divide_blocks() first when the grid is at 2*block)."""
+        _capi.check(self._lib.bbme_stage_regularize(self._ctx, level, block, lambda_multiplier))
+
+    def stage_get_mvs(self, level, block):
+        w, h, _, _ = self.level_geometry(level)
+        out = np.empty((h // block, w // block, 2), np.int16)
+        _capi.check(self._lib.bbme_stage_get_mvs(self._ctx, level, block, out.ctypes.data))
+        return out
+
+    def stage_set_mvs(self, level, block, mvs):
+        w, h, _, _ = self.level_geometry(level)
+        mvs = np.ascontiguousarray(mvs, np.int16)
+        assert mvs.shape == (h // block, w // block, 2)
+        _capi.check(self._lib.bbme_stage_set_mvs(self._ctx, level, block, mvs.ctypes.data))
+
+    def stage_expand(self):
+        _capi.check(self._lib.bbme_stage_expand(self._ctx))
+
+    def last_sweep_passes(self):
+        v = (C.c_int * 2)()
+        _capi.check(self._lib.bbme_last_sweep_passes(self._ctx, v))
+        return v[0], v[1]
+
+    def set_profiling(self, enabled):
+        _capi.check(self._lib.bbme_set_profiling(self._ctx, int(enabled)))
+
+    def timings(self):
+        v = [C.c_float() for _ in range(5)]
+        _capi.check(self._lib.bbme_get_timings(self._ctx, *[C.byref(x) for x in v]))
+        return dict(zip(("total_ms", "search_ms", "regularize_ms", "expand_ms", "search_level0_ms"),
+                        [x.value for x in v]))
+
+
+def plan_padding(width, height, search_size, block_size):
+    """padded_width, padded_height, padding_x, padding_y of MF::MF (motion_framework.cpp:14-54)."""
+    p = _capi.make_params(search_size, block_size)
+    v = [C.c_int() for _ in range(4)]
+    _capi.check(_capi.lib().bbme_plan_padding(width, height, C.byref(p), *[C.byref(x) for x in v]))
+    return tuple(x.value for x in v)
+
+
+def pad_zero(img, pad_x, pad_y):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.empty((h + 2 * pad_y, w + 2 * pad_x), np.uint8)
+    _capi.check(_capi.lib().bbme_pad_zero_host(img.ctypes.data, w, h, w, pad_x, pad_y, out.ctypes.data))
+    return out
+
+
+def pyr_down(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.empty((h // 2, w // 2), np.uint8)
+    _capi.check(_capi.lib().bbme_pyr_down_host(img.ctypes.data, w, h, out.ctypes.data))
+    return out
+
+
+def resize_x4(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.empty((h * 4, w * 4), np.uint8)
+    _capi.check(_capi.lib().bbme_resize_x4_host(img.ctypes.data, w, h, out.ctypes.data))
+    return out

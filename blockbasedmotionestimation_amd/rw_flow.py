@@ -1,0 +1,52 @@
+"""Python mirror of the reference's Flow class (rw_flow.h:9-38) over the C-ABI.
+
+ReadFlowFile / WriteFlowFile / CalculateMSE keep the reference's names and argument order.
+MotionToColor and ShowImage (visualisation, rw_flow.cpp:202-307,334-340) are out of scope.
+Errors the reference reports with a message and exit(1) raise BbmeError instead.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _capi
+
+
+class Flow:
+    def ReadFlowFile(self, filename):
+        """Flow::ReadFlowFile (rw_flow.cpp:50-136) -> (H, W, 2) float32."""
+        w, h = C.c_int(), C.c_int()
+        data = C.POINTER(C.c_float)()
+        fn = None if filename is None else os.fsencode(filename)
+        _capi.check(_capi.lib().bbme_flo_read(fn, C.byref(w), C.byref(h), C.byref(data)))
+        try:
+            return np.ctypeslib.as_array(data, shape=(h.value, w.value, 2)).copy()
+        finally:
+            _capi.lib().bbme_free(data)
+
+    def WriteFlowFile(self, img, filename):
+        """Flow::WriteFlowFile (rw_flow.cpp:139-200)."""
+        img = np.ascontiguousarray(img, np.float32)
+        if img.ndim != 3 or img.shape[2] != 2:
+            raise _capi.BbmeError(_capi.ERR_INVALID, "WriteFlowFile: image must have 2 bands")
+        fn = None if filename is None else os.fsencode(filename)
+        _capi.check(_capi.lib().bbme_flo_write(fn, img.shape[1], img.shape[0], img.ctypes.data))
+
+    def CalculateMSE(self, gtruth, flow):
+        """Flow::CalculateMSE (rw_flow.cpp:309-332): average end-point error over known GT pixels."""
+        g = np.ascontiguousarray(gtruth, np.float32)
+        f = np.ascontiguousarray(flow, np.float32)
+        if g.shape != f.shape:
+            raise _capi.BbmeError(_capi.ERR_INVALID, "CalculateMSE: shapes differ")
+        out = C.c_double()
+        _capi.check(_capi.lib().bbme_calculate_mse(g.ctypes.data, f.ctypes.data, g.shape[1], g.shape[0], C.byref(out)))
+        return out.value
+
+
+def subsample_div4(flow_padded, pad_x, pad_y, out_width, out_height):
+    """main_class.cpp:58-70: strip padding, every 4th pixel, divide by 4."""
+    f = np.ascontiguousarray(flow_padded, np.float32)
+    out = np.zeros((out_height, out_width, 2), np.float32)
+    _capi.check(_capi.lib().bbme_subsample_div4(f.ctypes.data, f.shape[1], f.shape[0], pad_x, pad_y,
+                                                out.ctypes.data, out_width, out_height))
+    return out

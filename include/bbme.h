@@ -1,0 +1,159 @@
+/*
+ * bbme.h -- C-ABI of libbbme.so: MI355X-native block-matching motion estimation.
+ *
+ * Drop-in boundary for the hot path of ashish-nr/BlockBasedMotionEstimation:
+ * MF::calcMotionBlockMatching() and everything it calls (pyramidal SAD spiral
+ * full search + 8-neighbour MV regularisation), plus the Flow .flo codec and
+ * the EPE evaluation.  The reference has no FFI; its boundary is the two C++
+ * classes MF (motion_framework.h:9-54) and Flow (rw_flow.h:9-38).  Each entry
+ * point below names the reference interface it replaces (paths relative to the
+ * reference repository root).  All signatures are plain C: pointers and sizes,
+ * no C++ or torch types.  Every function returns 0 (BBME_OK) or a negative
+ * bbme_status; bbme_last_error() gives the message (thread-local).  Nothing in
+ * this library ever calls exit() or abort().
+ *
+ * The compute path is HIP on gfx950 only.  There is no CPU fallback: entry
+ * points that need the GPU fail with BBME_ERR_HIP when no device is usable.
+ */
+#ifndef BBME_H
+#define BBME_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BBME_MAX_LEVELS 8
+
+typedef enum {
+    BBME_OK = 0,
+    BBME_ERR_INVALID = -1,      /* bad argument (null, non power-of-two block, sizes...)          */
+    BBME_ERR_PADDING = -2,      /* "Could not find any multiples of the block size" (:21-26)       */
+    BBME_ERR_ODD_PADDING = -3,  /* padded - original is odd: the reference mis-sizes the image     */
+    BBME_ERR_DEGENERATE = -4,   /* < 2 blocks in a dimension at some level: reference reads OOB    */
+    BBME_ERR_HIP = -5,          /* HIP runtime error / no gfx950 device                            */
+    BBME_ERR_IO = -6,           /* .flo file errors (the reference prints and exit(1)s)            */
+    BBME_ERR_STATE = -7,        /* call sequence error (e.g. estimate before frames were set)      */
+    BBME_ERR_UNSUPPORTED = -8   /* legal in the reference but outside what the kernels implement   */
+} bbme_status;
+
+/* Parameters of MF::MF (motion_framework.h:12).  Index 0 = finest level,
+ * num_levels-1 = coarsest (motion_framework.cpp:71-72,93-94,115).
+ * search_size is the search-window SIDE LENGTH (range = (search_size-block_size)>>1). */
+typedef struct {
+    int num_levels;
+    int block_size[BBME_MAX_LEVELS];
+    int search_size[BBME_MAX_LEVELS];
+} bbme_params;
+
+typedef struct bbme_ctx bbme_ctx;
+
+/* ---- no GPU needed ---------------------------------------------------------------- */
+
+const char *bbme_version(void);
+const char *bbme_last_error(void);
+
+/* Padding search of MF::MF (motion_framework.cpp:14-54): public fields
+ * padded_width/padded_height/padding_x/padding_y (motion_framework.h:16-19). */
+int bbme_plan_padding(int width, int height, const bbme_params *params,
+                      int *padded_width, int *padded_height, int *pad_x, int *pad_y);
+
+/* Host-side pieces of MF::MF, exposed for callers that build planes themselves:
+ * zero border (copyMakeBorder, :60-61) and one pyrDown step (:89-90). */
+int bbme_pad_zero_host(const uint8_t *src, int width, int height, int pitch,
+                       int pad_x, int pad_y, uint8_t *dst);
+int bbme_pyr_down_host(const uint8_t *src, int src_width, int src_height, uint8_t *dst);
+/* cv::resize(..., 4, 4, INTER_LINEAR) of main_class.cpp:32-33 (8-bit fixed point). */
+int bbme_resize_x4_host(const uint8_t *src, int src_width, int src_height, uint8_t *dst);
+
+/* Flow::ReadFlowFile (rw_flow.cpp:50-136).  *data is allocated by the library
+ * (width*height*2 floats, u,v interleaved, row-major); release with bbme_free. */
+int bbme_flo_read(const char *filename, int *width, int *height, float **data);
+/* Flow::WriteFlowFile (rw_flow.cpp:139-200). */
+int bbme_flo_write(const char *filename, int width, int height, const float *data);
+/* Flow::CalculateMSE (rw_flow.cpp:309-332): mean end-point error over known GT pixels. */
+int bbme_calculate_mse(const float *gtruth, const float *flow, int width, int height, double *out);
+/* main_class.cpp:58-70: strip padding, every 4th pixel, divide by 4. */
+int bbme_subsample_div4(const float *flow_padded, int padded_width, int padded_height,
+                        int pad_x, int pad_y, float *out, int out_width, int out_height);
+void bbme_free(void *p);
+
+/* ---- context: one per GPU stream (replaces an MF object) ---------------------------- */
+
+/* Allocates every device buffer for a (width x height) frame pair: padded planes of
+ * all levels, MV grids, work lists, the dense output.  device = HIP ordinal. */
+int bbme_create(const bbme_params *params, int width, int height, int device, bbme_ctx **out);
+int bbme_destroy(bbme_ctx *ctx);
+/* hipStream_t to run on (default: a stream the ctx creates).  Pass the raw handle. */
+int bbme_set_stream(bbme_ctx *ctx, void *hip_stream);
+int bbme_get_geometry(const bbme_ctx *ctx, int *padded_width, int *padded_height,
+                      int *pad_x, int *pad_y);
+int bbme_level_geometry(const bbme_ctx *ctx, int level, int *width, int *height,
+                        int *block_size, int *search_size);
+
+/* ---- inputs ------------------------------------------------------------------------- */
+
+/* MF::MF(image1, image2, ...) (motion_framework.cpp:4-111) for host images: pads with
+ * zeros, builds the pyramid with pyrDown on the host, uploads all planes. */
+int bbme_set_frames_host(bbme_ctx *ctx, const uint8_t *image1, const uint8_t *image2, int pitch);
+/* Same constructor for frames already resident in HBM (unpadded, width x height):
+ * zero padding and the whole pyrDown cascade run as HIP kernels on the ctx stream. */
+int bbme_set_frames_device(bbme_ctx *ctx, const uint8_t *d_image1, const uint8_t *d_image2, int pitch);
+/* Direct access to the ctx-owned padded planes of a level (device pointers, pitch ==
+ * level width) so a caller can fill or inspect them in place. */
+int bbme_level_planes_device(bbme_ctx *ctx, int level, uint8_t **d_image1, uint8_t **d_image2);
+/* Upload ready-made padded planes of one level (fixtures taken after the pyramid). */
+int bbme_set_level_planes_host(bbme_ctx *ctx, int level, const uint8_t *image1, const uint8_t *image2);
+int bbme_get_level_planes_host(bbme_ctx *ctx, int level, uint8_t *image1, uint8_t *image2);
+
+/* ---- the hot path ------------------------------------------------------------------- */
+
+/* MF::calcMotionBlockMatching() (motion_framework.cpp:113-219).  Enqueues the whole
+ * pyramid (search + regularisation of every level + dense expansion) on the ctx
+ * stream and returns without waiting; no host synchronisation inside. */
+int bbme_estimate(bbme_ctx *ctx);
+int bbme_synchronize(bbme_ctx *ctx);
+/* The cv::Mat returned by calcMotionBlockMatching (:218): dense padded H0 x W0
+ * float2 (u,v) = (dx,dy), device pointer, pitch == padded width. */
+int bbme_flow_device(bbme_ctx *ctx, const float **d_flow);
+/* Synchronises, then copies the dense padded field to the host. */
+int bbme_get_flow_host(bbme_ctx *ctx, float *flow /* padded_h * padded_w * 2 */);
+/* Compact result: one int16 (dx,dy) pair per 2x2 cell of level 0 ((H0/2) x (W0/2)). */
+int bbme_get_cells_host(bbme_ctx *ctx, int16_t *cells);
+
+/* ---- single stages, for parity tests against the reference's private methods -------- */
+
+/* copyMVs (:828-843) + calcLevelBM (:226-244) of one level.  Leaves that level's MV
+ * grid at block size block_size[level]. */
+int bbme_stage_search(bbme_ctx *ctx, int level);
+/* One regularize_MVs() sweep (:424-530) at block size `block` with lambda_multiplier
+ * `mult` (lambda follows the reference's rule lambda = (B/2) * (B/block)).  `block` must
+ * equal the level's current grid block size, or half of it (then divide_blocks, :845-862,
+ * is applied first). */
+int bbme_stage_regularize(bbme_ctx *ctx, int level, int block, int mult);
+/* Current MV grid of a level, sampled at `block` (<= current grid block size), as
+ * int16 (dx,dy) per block, row-major (height/block rows x width/block cols). */
+int bbme_stage_get_mvs(bbme_ctx *ctx, int level, int block, int16_t *mvs);
+/* Overwrite a level's MV grid at block size `block` (makes it the current grid). */
+int bbme_stage_set_mvs(bbme_ctx *ctx, int level, int block, const int16_t *mvs);
+/* copy_to_all_pixels (:815-826) on level 0 after its last divide: fills the dense field. */
+int bbme_stage_expand(bbme_ctx *ctx);
+/* Fix-up passes the last sweep needed after its first full pass (diagnostic). */
+int bbme_last_sweep_passes(bbme_ctx *ctx, int *passes);
+
+/* Times (ms, HIP events on the ctx stream) of the last bbme_estimate when profiling
+ * was enabled: total, and the sum over levels of search / regulariser / expand kernels. */
+int bbme_set_profiling(bbme_ctx *ctx, int enabled);
+int bbme_get_timings(bbme_ctx *ctx, float *total_ms, float *search_ms, float *regularize_ms,
+                     float *expand_ms, float *search_level0_ms);
+
+/* Instruction probes used by the GPU test-suite: checks v_sad_u8, v_alignbyte_b32,
+ * v_qsad_pk_u16_u8 and v_sad_u16 against a scalar model on 65536 random operands.
+ * mismatches[0..3] receive the number of disagreements per instruction, in that order. */
+int bbme_selftest_isa(int device, int *mismatches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BBME_H */

@@ -1,0 +1,174 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against the CPU oracle on the
+same seeded inputs.  Bar: bit-exact motion vectors (integer work) at every stage of the
+reference's schedule -- after the search of each level and after every regulariser sweep --
+and bit-exact dense float flow at the end."""
+import numpy as np
+import pytest
+
+from helpers import compare_stagewise, gpu_schedule, oracle_schedule
+
+pytestmark = pytest.mark.gpu
+
+
+def test_isa_probes(bbme):
+    """v_sad_u8 / v_alignbyte_b32 / v_qsad_pk_u16_u8 / v_sad_u16 behave as the kernels assume."""
+    import ctypes as C
+    from blockbasedmotionestimation_amd import _capi
+    mism = (C.c_int * 4)()
+    _capi.check(_capi.lib().bbme_selftest_isa(0, mism))
+    assert list(mism) == [0, 0, 0, 0], "sad_u8, alignbyte, qsad_pk_u16_u8, sad_u16 mismatches: %s" % list(mism)
+
+
+CASES = [
+    # (width, height, search_size[], block_size[], seed, max_motion)
+    (320, 208, [30, 30, 30], [16, 16, 16], 1001, 12),          # cfg1-like: B=16, R=7, 3 levels
+    (256, 192, [48], [16], 1002, 14),                           # single level, R=16
+    (384, 256, [48, 48, 48], [16, 16, 16], 1003, 24),           # cfg2-like, 3 levels
+    (512, 384, [80, 80, 80], [16, 16, 16], 1004, 40),           # R=32 (cfg3's search), windows leave the image
+    (256, 256, [72, 72], [8, 8], 1005, 20),                     # cfg4-like: B=8, R=32
+    (512, 512, [64, 64, 64], [32, 32, 32], 1006, 30),           # the reference's own literals: B=32, search 64
+    (320, 256, [24, 40, 30], [8, 16, 8], 1007, 10),             # different block / search per level
+    (200, 120, [30, 30], [16, 16], 1008, 6),                    # needs padding in both dimensions
+    (256, 128, [17, 21], [16, 16], 1009, 3),                    # odd shift (search-block odd), tiny ranges
+    (128, 128, [16], [16], 1010, 0),                            # search_size == block_size: centre only
+    (256, 192, [12, 12], [4, 4], 1011, 5),                      # B=4
+]
+
+
+@pytest.mark.parametrize("w,h,search,block,seed,mm", CASES)
+def test_stagewise_parity(bbme, oracle, w, h, search, block, seed, mm):
+    f1, f2, _ = bbme.synth_pair(w, h, seed, max_motion=mm)
+    compare_stagewise(bbme, oracle, f1, f2, search, block)
+
+
+def test_flat_and_zero_frames_tie_breaking(bbme, oracle):
+    """All-equal SADs everywhere: the winner is decided purely by spiral order (search) and by
+    candidate order (regulariser)."""
+    z = np.zeros((128, 192), np.uint8)
+    compare_stagewise(bbme, oracle, z, z, [48, 48], [16, 16])
+    c = np.full((128, 192), 77, np.uint8)
+    compare_stagewise(bbme, oracle, c, c, [30, 30], [16, 16])
+    # flat frame1, textured frame2 and vice versa
+    f1, f2, _ = bbme.synth_pair(192, 128, 5, max_motion=8)
+    compare_stagewise(bbme, oracle, c, f2, [30, 30], [16, 16])
+    compare_stagewise(bbme, oracle, f1, c, [30, 30], [16, 16])
+
+
+def test_periodic_texture_many_ties(bbme, oracle):
+    """Stripes and checkerboards: many candidates share the minimal SAD."""
+    y, x = np.mgrid[0:192, 0:256]
+    stripes = ((x // 4) % 2 * 200).astype(np.uint8)
+    checker = (((x // 8) + (y // 8)) % 2 * 255).astype(np.uint8)
+    compare_stagewise(bbme, oracle, stripes, np.roll(stripes, 3, axis=1), [48, 48], [16, 16])
+    compare_stagewise(bbme, oracle, checker, np.roll(checker, (5, -2), axis=(0, 1)), [48, 48], [16, 16])
+
+
+def test_large_motion_predictions_leave_image(bbme, oracle):
+    """Coarse MVs doubled at the next level push predictions outside the image: those blocks
+    take a zero MV without searching (motion_framework.cpp:304-310)."""
+    rng = np.random.default_rng(7)
+    f1 = rng.integers(0, 256, (256, 320), dtype=np.uint8)
+    f2 = np.roll(f1, (37, -45), axis=(0, 1))
+    compare_stagewise(bbme, oracle, f1, f2, [80, 80, 80], [16, 16, 16])
+
+
+def test_noise_frames(bbme, oracle):
+    """Uncorrelated noise: regulariser candidates often point outside the image (FLT_MAX energy)."""
+    rng = np.random.default_rng(11)
+    f1 = rng.integers(0, 256, (192, 256), dtype=np.uint8)
+    f2 = rng.integers(0, 256, (192, 256), dtype=np.uint8)
+    compare_stagewise(bbme, oracle, f1, f2, [48, 48], [16, 16])
+    compare_stagewise(bbme, oracle, f1, f2, [40, 40], [8, 8])
+
+
+def test_full_pipeline_host_frames(bbme, oracle):
+    """MF(image1, image2, ...).calcMotionBlockMatching() end to end, including the product's own
+    host padding + pyrDown, against the oracle's."""
+    f1, f2, _ = bbme.synth_pair(584, 388, 1010, max_motion=7)          # RubberWhale geometry, cfg1
+    search, block = [30, 30, 30], [16, 16, 16]
+    omf = oracle.OracleMF(f1, f2, search, block)
+    exp = omf.calc_motion_block_matching()
+    mf = bbme.MF(f1, f2, search, block, 3)
+    assert (mf.padded_width, mf.padded_height, mf.padding_x, mf.padding_y) == (640, 448, 28, 30)
+    for lvl in range(3):
+        a, b = mf.get_level_planes(lvl)
+        assert np.array_equal(a, omf.image(lvl, 1)) and np.array_equal(b, omf.image(lvl, 2))
+    got = mf.calcMotionBlockMatching()
+    assert got.dtype == np.float32 and got.shape == (448, 640, 2)
+    assert np.array_equal(got, exp)
+    # graph replay: a second call on the same context gives the same field
+    assert np.array_equal(mf.calcMotionBlockMatching(), exp)
+    cells = mf.get_cells()
+    assert np.array_equal(cells.astype(np.float32), exp[::2, ::2])
+    assert np.array_equal(np.repeat(np.repeat(cells, 2, 0), 2, 1).astype(np.float32), exp)
+    mf.close()
+
+
+def test_device_frames_gpu_pyramid(bbme, oracle):
+    """Frames already in HBM: zero padding and the pyrDown cascade as HIP kernels."""
+    import torch
+    f1, f2, _ = bbme.synth_pair(600, 410, 1020, max_motion=10)
+    search, block = [48, 48, 48], [16, 16, 16]
+    omf = oracle.OracleMF(f1, f2, search, block)
+    t1 = torch.from_numpy(f1).cuda()
+    t2 = torch.from_numpy(f2).cuda()
+    mf = bbme.MF(t1, t2, search, block, 3, frames_on_device=True)
+    mf.synchronize()
+    for lvl in range(3):
+        a, b = mf.get_level_planes(lvl)
+        assert np.array_equal(a, omf.image(lvl, 1)), "image1 plane of level %d" % lvl
+        assert np.array_equal(b, omf.image(lvl, 2)), "image2 plane of level %d" % lvl
+    got = mf.calcMotionBlockMatching()
+    assert np.array_equal(got, omf.calc_motion_block_matching())
+    mf.close()
+
+
+def test_errors_through_the_boundary(bbme):
+    z = np.zeros((64, 64), np.uint8)
+    with pytest.raises(bbme.BbmeError) as e:          # one block per dimension at the coarsest level
+        bbme.MF(z, z, [30, 30], [16, 32])
+    assert e.value.status == -4
+    with pytest.raises(bbme.BbmeError) as e:          # no multiple below twice the size
+        bbme.MF(np.zeros((40, 40), np.uint8), np.zeros((40, 40), np.uint8), [80, 80, 80], [32, 32, 32])
+    assert e.value.status == -2
+    with pytest.raises(bbme.BbmeError):
+        bbme.MF(z, np.zeros((64, 32), np.uint8), [30], [16])
+    mf = bbme.MF(np.zeros((128, 128), np.uint8), np.zeros((128, 128), np.uint8), [30, 30], [16, 16])
+    with pytest.raises(bbme.BbmeError) as e:          # level 0 searched before level 1 is done
+        mf.stage_search(0)
+    assert e.value.status == -7
+    mf.stage_search(1)
+    with pytest.raises(bbme.BbmeError) as e:          # sweep at 4 while the grid is at 16
+        mf.stage_regularize(1, 4, 1)
+    assert e.value.status == -7
+    mf.close()
+
+
+@pytest.mark.parametrize("cfg", ["cfg2_1080p", "cfg3_4k", "cfg4_4k_b8"])
+def test_full_size_properties(bbme, cfg):
+    """BASELINE.json's full sizes, through properties that need no oracle run:
+    (1) determinism / replay, (2) the dense field is constant on 2x2 cells and equals the compact
+    cells, (3) a globally translated frame yields exactly that translation wherever the block and
+    its whole neighbourhood stay inside both frames, (4) every MV is an integer."""
+    w, h, search, block = {
+        "cfg2_1080p": (1920, 1080, [48] * 3, [16] * 3),
+        "cfg3_4k": (3840, 2160, [80] * 4, [16] * 4),
+        "cfg4_4k_b8": (3840, 2160, [72] * 4, [8] * 4),
+    }[cfg]
+    rng = np.random.default_rng(99)
+    big = rng.integers(0, 256, (h + 64, w + 64), dtype=np.uint8)
+    dx, dy = 5, -3
+    f1 = big[32:32 + h, 32:32 + w]
+    f2 = big[32 - dy:32 - dy + h, 32 - dx:32 - dx + w]       # f2(y + dy, x + dx) == f1(y, x)
+    mf = bbme.MF(f1, f2, search, block, len(block))
+    a = mf.calcMotionBlockMatching()
+    b = mf.calcMotionBlockMatching()
+    assert np.array_equal(a, b)
+    assert np.array_equal(a, np.round(a))
+    cells = mf.get_cells()
+    assert np.array_equal(np.repeat(np.repeat(cells, 2, 0), 2, 1).astype(np.float32), a)
+    py, px = mf.padding_y, mf.padding_x
+    inner = a[py + 128:py + h - 128, px + 128:px + w - 128]
+    frac = np.mean((inner[..., 0] == dx) & (inner[..., 1] == dy))
+    assert frac == 1.0, "only %.4f of interior pixels carry the true translation" % frac
+    mf.close()
