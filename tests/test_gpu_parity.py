@@ -41,6 +41,31 @@ def test_stagewise_parity(bbme, oracle, w, h, search, block, seed, mm):
     compare_stagewise(bbme, oracle, f1, f2, search, block)
 
 
+@pytest.mark.parametrize("name", ["hotpath_b16_r7_l3", "hotpath_b16_r16_l2", "hotpath_b8_r32_l2",
+                                  "hotpath_b32_r16_l2", "hotpath_mixed_l3"])
+def test_golden_fixtures(bbme, name):
+    """Committed vectors (tests/golden/*.npz): planes in, every intermediate MV grid and the final
+    dense flow out.  No oracle call on this path."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    block = g["block_size"].tolist()
+    L = len(block)
+    mf = bbme.MF(g["frame1"], g["frame2"], g["search_size"].tolist(), block, L)
+    assert [mf.padded_width, mf.padded_height, mf.padding_x, mf.padding_y] == g["geometry"].tolist()
+    for lvl in range(L):
+        mf.set_level_planes(lvl, g["plane1_l%d" % lvl], g["plane2_l%d" % lvl])
+    got = []
+    flow = gpu_schedule(mf, L, block, lambda kind, lvl, b, mv: got.append((kind, lvl, b, mv)))
+    keys = [str(k) for k in g["stages"]]
+    assert len(keys) == len(got)
+    for key, (kind, lvl, b, mv) in zip(keys, got):
+        assert key.endswith("%s_l%d_b%d" % (kind, lvl, b))
+        assert np.array_equal(g[key].astype(np.int32), mv), key
+    assert np.array_equal(g["flow"], flow)
+    mf.close()
+
+
 def test_flat_and_zero_frames_tie_breaking(bbme, oracle):
     """All-equal SADs everywhere: the winner is decided purely by spiral order (search) and by
     candidate order (regulariser)."""

@@ -1,0 +1,149 @@
+"""CPU tests of the product's host side (no GPU): the C-ABI library loads and exports every symbol
+include/bbme.h declares; MF::MF's padding / pyramid, the .flo codec and the EPE in libbbme.so agree
+with the oracle and with the reference-made fixtures; error behaviour without a device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+
+def test_library_exports_every_declared_symbol(bbme):
+    from blockbasedmotionestimation_amd import _capi
+    header = open(os.path.join(ROOT, "include", "bbme.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(bbme_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 30
+    lib = C.CDLL(_capi.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, "declared in bbme.h but not exported: %s" % missing
+    assert declared == set(_capi.SIGNATURES), (declared ^ set(_capi.SIGNATURES))
+    assert _capi.lib().bbme_version().startswith(b"bbme")
+
+
+def test_no_cpu_fallback_without_device(bbme):
+    """The product fails loudly when no GPU can be used: there is no CPU compute path."""
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present")
+    z = np.zeros((128, 128), np.uint8)
+    with pytest.raises(bbme.BbmeError) as e:
+        bbme.MF(z, z, [30, 30], [16, 16])
+    assert e.value.status == -5 and "no CPU fallback" in e.value.message
+
+
+def test_product_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under the product package may reference it."""
+    pkg = os.path.join(ROOT, "blockbasedmotionestimation_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                for needle in ("from oracle", "import oracle", "bbme_oracle", "orc_", "oracle/_build", "oracle/_ref"):
+                    assert needle not in text, "%s mentions %r" % (f, needle)
+
+
+@pytest.mark.parametrize("w,h,blocks", [(584, 388, [16, 16, 16]), (1920, 1080, [16, 16, 16]), (3840, 2160, [16] * 4),
+                                         (3840, 2160, [8] * 4), (2336, 1552, [32] * 4), (200, 120, [16, 16]),
+                                         (640, 480, [16]), (100, 100, [8, 16, 8]), (333, 77, [4, 4])])
+def test_padding_plan_matches_oracle(bbme, oracle, w, h, blocks):
+    rc, pw, ph, px, py = oracle.plan_padding(w, h, blocks)
+    if rc == 0:
+        assert bbme.plan_padding(w, h, [b + 14 for b in blocks], blocks) == (pw, ph, px, py)
+    else:
+        with pytest.raises(bbme.BbmeError) as e:
+            bbme.plan_padding(w, h, [b + 14 for b in blocks], blocks)
+        assert e.value.status == {-1: -2, -2: -3}[rc]
+
+
+def test_padding_plan_exhaustive_small(bbme, oracle):
+    for blocks in ([16], [8, 8], [16, 16, 16], [4, 8]):
+        for w in range(20, 150, 7):
+            for h in (33, 64, 97, 128):
+                rc, pw, ph, px, py = oracle.plan_padding(w, h, blocks)
+                try:
+                    got = bbme.plan_padding(w, h, [b + 2 for b in blocks], blocks)
+                    assert rc == 0 and got == (pw, ph, px, py), (w, h, blocks)
+                except bbme.BbmeError as e:
+                    assert rc != 0 and e.status == {-1: -2, -2: -3}[rc], (w, h, blocks, rc, e.status)
+
+
+def test_known_geometries(bbme):
+    assert bbme.plan_padding(584, 388, [30] * 3, [16] * 3) == (640, 448, 28, 30)            # cfg1
+    assert bbme.plan_padding(1920, 1080, [48] * 3, [16] * 3) == (1920, 1088, 0, 4)           # cfg2
+    assert bbme.plan_padding(3840, 2160, [80] * 4, [16] * 4) == (3840, 2176, 0, 8)           # cfg3
+    assert bbme.plan_padding(2336, 1552, [64] * 4, [32] * 4) == (2560, 1792, 112, 120)       # main_class.cpp:19-21
+
+
+def test_pad_pyrdown_resize_match_oracle(bbme, oracle):
+    rng = np.random.default_rng(3)
+    for (h, w) in [(48, 64), (50, 70), (2, 2), (6, 4), (33, 31)]:
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        assert np.array_equal(bbme.pad_zero(img, 5, 3), oracle.pad_zero(img, 5, 3))
+        assert np.array_equal(bbme.pyr_down(img), oracle.pyr_down(img))
+        assert np.array_equal(bbme.resize_x4(img), oracle.resize_linear_x4(img))
+    # constant images stay constant, a pyrDown of a ramp stays a ramp in the interior
+    c = np.full((32, 32), 201, np.uint8)
+    assert np.all(bbme.pyr_down(c) == 201) and np.all(bbme.resize_x4(c) == 201)
+
+
+def test_flow_class_codec_and_epe(bbme, oracle, tmp_path):
+    flow = bbme.Flow()
+    ref_file = os.path.join(GOLDEN, "flo_ramp_ref.flo")
+    f = flow.ReadFlowFile(ref_file)
+    assert np.array_equal(f, oracle.flo_read(ref_file))
+    out = tmp_path / "w.flo"
+    flow.WriteFlowFile(f, str(out))
+    assert out.read_bytes() == open(ref_file, "rb").read()
+    venus = flow.ReadFlowFile(os.path.join(GOLDEN, "gt_Venus_flow10.flo"))
+    assert venus.shape == (380, 420, 2)
+    rng = np.random.default_rng(9)
+    est = venus + rng.normal(0, 1.5, venus.shape).astype(np.float32)
+    est[5, 5] = 2e9                                              # estimate may be anything; GT decides "unknown"
+    gt = venus.copy()
+    gt[10:20, 10:30] = 1.666666752e9                             # Middlebury's unknown marker
+    gt[3, 3, 1] = np.nan
+    assert flow.CalculateMSE(gt, est) == oracle.calculate_mse(gt, est)
+    assert flow.CalculateMSE(venus, venus) == 0.0
+    sub = bbme.subsample_div4(np.arange(64 * 48 * 2, dtype=np.float32).reshape(48, 64, 2), 4, 8, 14, 8)
+    assert np.array_equal(sub, oracle.subsample_div4(np.arange(64 * 48 * 2, dtype=np.float32).reshape(48, 64, 2), 4, 8, 14, 8))
+
+
+def test_flow_errors_raise_instead_of_exit(bbme, tmp_path):
+    flow = bbme.Flow()
+    good = open(os.path.join(GOLDEN, "flo_ramp_ref.flo"), "rb").read()
+    for name, data in {"short.flo": good[:-1], "long.flo": good + b"x", "tag.flo": b"XXXX" + good[4:]}.items():
+        p = tmp_path / name
+        p.write_bytes(data)
+        with pytest.raises(bbme.BbmeError) as e:
+            flow.ReadFlowFile(str(p))
+        assert e.value.status == -6
+    for bad in (str(tmp_path / "nodot"), str(tmp_path / "x.txt"), None):
+        with pytest.raises(bbme.BbmeError):
+            flow.WriteFlowFile(np.zeros((2, 2, 2), np.float32), bad)
+    with pytest.raises(bbme.BbmeError):
+        flow.ReadFlowFile(None)
+    with pytest.raises(bbme.BbmeError):
+        flow.ReadFlowFile(str(tmp_path / "absent.flo"))
+
+
+def test_parameter_validation(bbme):
+    for search, block in [([30], [12]), ([30], [2]), ([30], [128]), ([0], [16]), ([400], [16])]:
+        with pytest.raises(bbme.BbmeError):
+            bbme.plan_padding(640, 480, search, block)
+    with pytest.raises(ValueError):
+        bbme.plan_padding(640, 480, [30, 30], [16])
+
+
+def test_synth_pair_is_deterministic(bbme):
+    a = bbme.synth_pair(96, 64, 77, max_motion=5)
+    b = bbme.synth_pair(96, 64, 77, max_motion=5)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert a[0].dtype == np.uint8 and a[0].shape == (64, 96) and a[2].shape == (64, 96, 2)
+    # noise-free pair: inside a motion tile, frame2 is frame1 moved by the tile's vector
+    f1, f2, mo = bbme.synth_pair(96, 64, 78, max_motion=5, noise=0, tiles=1)
+    dx, dy = (int(v) for v in mo[0, 0])
+    ys, xs = np.mgrid[8:56, 8:88]
+    assert np.array_equal(f2[ys + dy, xs + dx], f1[ys, xs])

@@ -1,0 +1,202 @@
+"""CPU tests of the oracle itself: pin what can be pinned (the .flo codec and EPE against the
+reference's own Middlebury code and ground-truth files), and cross-check the unpinned hot-path
+restatement against an independently structured numpy restatement and the committed vectors."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from helpers import oracle_schedule
+
+REF_GT = "/root/reference/middlebury/gt-flow"
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+GOLDEN_CASES = ["hotpath_b16_r7_l3", "hotpath_b16_r16_l2", "hotpath_b8_r32_l2", "hotpath_b32_r16_l2",
+                "hotpath_mixed_l3"]
+
+
+# ---- spiral ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shift", [0, 1, 2, 3, 4, 5, 14, 15, 16, 32, 33, 64, 65, 126])
+def test_spiral_walk_covers_square_once_and_matches_closed_form(oracle, shift):
+    from oracle import bbme_numpy
+    dx, dy = oracle.spiral_walk(shift)
+    R = max(0, shift >> 1)
+    assert len(dx) == (2 * R + 1) ** 2
+    assert dx[0] == 0 and dy[0] == 0
+    cells = set(zip(dx.tolist(), dy.tolist()))
+    assert len(cells) == len(dx)
+    assert cells == {(x, y) for x in range(-R, R + 1) for y in range(-R, R + 1)}
+    for rank in range(len(dx)):
+        assert bbme_numpy.spiral_rank(int(dx[rank]), int(dy[rank])) == rank
+
+
+# ---- hot path: C oracle vs committed vectors vs numpy restatement --------------------------------
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_oracle_reproduces_golden_vectors(oracle, name):
+    g = load_golden(name)
+    L = len(g["block_size"])
+    omf = oracle.OracleMF(planes1=[g["plane1_l%d" % l] for l in range(L)],
+                          planes2=[g["plane2_l%d" % l] for l in range(L)],
+                          search_size=g["search_size"].tolist(), block_size=g["block_size"].tolist())
+    got = []
+    flow = oracle_schedule(omf, L, lambda kind, lvl, b, mv: got.append((kind, lvl, b, mv)))
+    keys = [str(k) for k in g["stages"]]
+    assert len(keys) == len(got)
+    for key, (kind, lvl, b, mv) in zip(keys, got):
+        assert key.endswith("%s_l%d_b%d" % (kind, lvl, b))
+        assert np.array_equal(g[key], mv), key
+    assert np.array_equal(g["flow"], flow)
+    # and the one-call orchestrator gives the same field as the stage-by-stage drive
+    omf2 = oracle.OracleMF(g["frame1"], g["frame2"], g["search_size"].tolist(), g["block_size"].tolist())
+    assert [omf2.padded_width, omf2.padded_height, omf2.padding_x, omf2.padding_y] == g["geometry"].tolist()
+    assert np.array_equal(omf2.calc_motion_block_matching(), g["flow"])
+
+
+@pytest.mark.parametrize("name", ["hotpath_b16_r7_l3", "hotpath_b8_r32_l2", "hotpath_mixed_l3"])
+def test_numpy_restatement_agrees_with_c_oracle(name):
+    from oracle import bbme_numpy
+    g = load_golden(name)
+    L = len(g["block_size"])
+    got = []
+    flow = bbme_numpy.run([g["plane1_l%d" % l] for l in range(L)], [g["plane2_l%d" % l] for l in range(L)],
+                          g["search_size"].tolist(), g["block_size"].tolist(),
+                          lambda kind, lvl, b, mv: got.append((kind, lvl, b, mv)))
+    keys = [str(k) for k in g["stages"]]
+    assert len(keys) == len(got)
+    for key, (kind, lvl, b, mv) in zip(keys, got):
+        assert np.array_equal(g[key].astype(np.int64), mv), key
+    assert np.array_equal(g["flow"], flow)
+
+
+def test_sad_cache_is_pure_memoisation(oracle, bbme):
+    """fast_array (motion_framework.h:46) never changes a result."""
+    f1, f2, _ = bbme.synth_pair(224, 160, 31, max_motion=9)
+    a = oracle.OracleMF(f1, f2, [40, 40], [16, 16], use_cache=True).calc_motion_block_matching()
+    b = oracle.OracleMF(f1, f2, [40, 40], [16, 16], use_cache=False).calc_motion_block_matching()
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("seed,w,h,search,block", [(41, 256, 160, [48, 48], [16, 16]), (42, 192, 128, [40, 24], [8, 8]),
+                                                    (43, 256, 256, [64, 64], [32, 32])])
+def test_fixed_point_schedule_equals_raster_sweep(oracle, bbme, seed, w, h, search, block):
+    """The GPU's schedule (pass 1 with new := old, then dirty fix-up passes to convergence) gives the
+    same field as the reference's in-place raster sweep, sweep after sweep."""
+    f1, f2, _ = bbme.synth_pair(w, h, seed, max_motion=12)
+    L = len(block)
+    a = oracle.OracleMF(f1, f2, search, block)
+    b = oracle.OracleMF(f1, f2, search, block)
+    for lvl in range(L - 1, -1, -1):
+        B = block[lvl]
+        for m in (a, b):
+            if lvl != L - 1:
+                m.copy_mvs(lvl)
+            m.calc_level_bm(lvl)
+        bs, lam = B, float(B // 2)
+        while bs > 1:
+            for mult in (1, 2):
+                for m in (a, b):
+                    m.set_block_size(lvl, bs)
+                    m.set_lambda(lvl, lam)
+                a.regularize_mvs(lvl, mult)
+                passes, evaluated = b.regularize_fixpoint(lvl, mult)
+                assert passes >= 1 and evaluated[0] == (a.level_shape(lvl)[0] // bs) * (a.level_shape(lvl)[1] // bs)
+                assert np.array_equal(a.block_mvs(lvl, bs), b.block_mvs(lvl, bs))
+            for m in (a, b):
+                m.divide_blocks(lvl)
+            bs >>= 1
+            lam *= 2
+        for m in (a, b):
+            m.set_block_size(lvl, B)
+
+
+def test_translation_is_recovered(oracle):
+    rng = np.random.default_rng(5)
+    big = rng.integers(0, 256, (200, 264), dtype=np.uint8)
+    f1 = big[20:20 + 160, 20:20 + 224]
+    f2 = big[20 - 4:20 - 4 + 160, 20 + 6:20 + 6 + 224]          # f2(y+4, x-6) == f1(y, x)
+    flow = oracle.OracleMF(f1, f2, [40, 40], [16, 16]).calc_motion_block_matching()
+    inner = flow[48:-48, 48:-48]
+    assert np.all(inner[..., 0] == -6) and np.all(inner[..., 1] == 4)
+
+
+# ---- .flo codec and EPE: pinned by the reference's own code and data ---------------------------
+def test_flo_reader_matches_reference_written_file(oracle):
+    """flo_ramp_ref.flo was written by the reference's WriteFlowFile (flowIO.cpp:95-133)."""
+    f = oracle.flo_read(os.path.join(GOLDEN, "flo_ramp_ref.flo"))
+    assert f.shape == (5, 7, 2)
+    y, x = np.mgrid[0:5, 0:7]
+    assert np.array_equal(f[..., 0], ((x - 3 * y) * 0.25).astype(np.float32))
+    assert np.array_equal(f[..., 1], ((7 * y - x) * 0.5).astype(np.float32))
+
+
+def test_flo_writer_is_byte_identical_to_reference(oracle, tmp_path):
+    ref = open(os.path.join(GOLDEN, "flo_ramp_ref.flo"), "rb").read()
+    f = oracle.flo_read(os.path.join(GOLDEN, "flo_ramp_ref.flo"))
+    out = tmp_path / "mine.flo"
+    oracle.flo_write(str(out), f)
+    assert out.read_bytes() == ref
+    assert ref[:4] == b"PIEH" and len(ref) == 12 + 7 * 5 * 8
+
+
+def test_gt_known_answers(oracle):
+    """Venus ground truth (a data file of the reference) against numbers computed with the
+    reference's own reader (tests/golden/gt_stats.json, made by make_golden.py)."""
+    stats = json.load(open(os.path.join(GOLDEN, "gt_stats.json")))["Venus"]
+    p = os.path.join(GOLDEN, "gt_Venus_flow10.flo")
+    assert hashlib.sha256(open(p, "rb").read()).hexdigest() == stats["sha256"]
+    f = oracle.flo_read(p)
+    assert f.shape == (stats["height"], stats["width"], 2)
+    unknown = (np.abs(f[..., 0]) > 1e9) | (np.abs(f[..., 1]) > 1e9) | np.isnan(f[..., 0]) | np.isnan(f[..., 1])
+    assert int(unknown.sum()) == stats["unknown"]
+    assert float(f[..., 0][~unknown].astype(np.float64).sum()) == pytest.approx(stats["sum_u"], rel=1e-12)
+    assert float(f[..., 1][~unknown].astype(np.float64).sum()) == pytest.approx(stats["sum_v"], rel=1e-12)
+    assert oracle.calculate_mse(f, f) == 0.0
+    g = f.copy()
+    g[..., 0] += 3.0
+    g[..., 1] -= 4.0
+    assert oracle.calculate_mse(f, g) == pytest.approx(5.0, abs=1e-5)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_GT), reason="reference data only exists in the build container")
+def test_all_gt_files_roundtrip_through_reference_and_oracle(oracle, tmp_path):
+    stats = json.load(open(os.path.join(GOLDEN, "gt_stats.json")))
+    for seq, st in stats.items():
+        p = os.path.join(REF_GT, seq, "flow10.flo")
+        raw = open(p, "rb").read()
+        assert len(raw) == st["bytes"] == 12 + 8 * st["width"] * st["height"]
+        assert hashlib.sha256(raw).hexdigest() == st["sha256"]
+        f = oracle.flo_read(p)
+        out = tmp_path / (seq + ".flo")
+        oracle.flo_write(str(out), f)
+        assert out.read_bytes() == raw
+        ref_out = tmp_path / (seq + "_ref.flo")
+        subprocess.check_call([oracle.FLO_REF, "roundtrip", str(out), str(ref_out)])
+        assert ref_out.read_bytes() == raw
+        unk = int(((np.abs(f) > 1e9).any(-1)).sum())
+        assert unk == st["unknown"]
+
+
+def test_flo_read_rejects_what_the_reference_rejects(oracle, tmp_path):
+    good = open(os.path.join(GOLDEN, "flo_ramp_ref.flo"), "rb").read()
+    cases = {"short.flo": good[:-4], "long.flo": good + b"\0", "tag.flo": b"HEIP" + good[4:],
+             "w0.flo": good[:4] + (0).to_bytes(4, "little") + good[8:],
+             "hbig.flo": good[:8] + (100000).to_bytes(4, "little") + good[12:], "hdr.flo": good[:10]}
+    for name, data in cases.items():
+        p = tmp_path / name
+        p.write_bytes(data)
+        with pytest.raises(IOError):
+            oracle.flo_read(str(p))
+    p = tmp_path / "ramp.txt"
+    p.write_bytes(good)
+    with pytest.raises(IOError):
+        oracle.flo_read(str(p))
+    with pytest.raises(IOError):
+        oracle.flo_read(str(tmp_path / "missing.flo"))
