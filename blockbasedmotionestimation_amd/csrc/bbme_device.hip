@@ -34,6 +34,14 @@ struct Level {
     int ncand = 0;
     int pitch_dw = 0;
     size_t lds_bytes = 0;
+    // fast search kernel (block 8 / 16)
+    bool fast = false;
+    uint16_t *rank_of = nullptr;
+    int rank_pitch = 0;
+    uint32_t *tasks = nullptr, *rounds = nullptr;
+    int nrounds = 0;
+    int fast_pitch_dw = 0;
+    size_t fast_lds_bytes = 0;
 };
 
 }  // namespace
@@ -47,11 +55,12 @@ struct bbme_ctx {
     std::vector<Level> lv;
     float *flow = nullptr;                        // dense padded H0 x W0 float2
     uint32_t *list[2] = {nullptr, nullptr};
-    uint32_t *bits[2] = {nullptr, nullptr};
+    uint32_t *qbits = nullptr;                    // QUEUED/BUSY, two bits per block
     uint32_t *counters = nullptr;                 // 8 words
     uint8_t *raw[2] = {nullptr, nullptr};         // unpadded frames for bbme_set_frames_device staging
     bool frames_set = false;
-    int fix_passes = 1;                           // global work-list passes before the tail kernel
+    int solve_wgs = 256;                          // workgroups of k_reg_solve (4 independent waves each)
+    bool force_generic_search = false;            // BBME_GENERIC_SEARCH=1: use k_search_generic everywhere
     bool use_graph = true;
     hipGraphExec_t graph_exec = nullptr;
     bool profiling = false;
@@ -88,9 +97,40 @@ void launch_search_t(const SearchArgs &a, int nblocks, size_t lds, hipStream_t s
     hipLaunchKernelGGL(k_search_generic<B>, dim3(nblocks), dim3(64), lds, s, a);
 }
 
+int launch_search_fast(bbme_ctx *c, int level)
+{
+    Level &L = c->lv[level];
+    FastSearchArgs a{};
+    a.image1 = L.img1; a.image2 = L.img2;
+    a.width = L.width; a.height = L.height;
+    a.range = L.range; a.spiral = L.spiral;
+    a.rank_of = L.rank_of; a.rank_pitch = L.rank_pitch;
+    a.tasks = L.tasks; a.rounds = L.rounds; a.nrounds = L.nrounds;
+    if (level + 1 < (int)c->lv.size()) {
+        Level &C = c->lv[level + 1];
+        if (C.cur_block != 2)
+            return bbme::fail(BBME_ERR_STATE, "level %d has not been regularised down to 2x2 blocks", level + 1);
+        a.coarse = C.grid[C.cur];
+        a.coarse_cols = C.width / 2;
+        a.coarse_block = C.block;
+    }
+    L.cur = 0; L.cur_block = L.block;
+    a.out = L.grid[0];
+    a.cols = L.width / L.block;
+    a.pitch_dw = L.fast_pitch_dw;
+    const int nblocks = (L.width / L.block) * (L.height / L.block);
+    if (L.block == 16)
+        hipLaunchKernelGGL(k_search_fast<16>, dim3(nblocks), dim3(64), L.fast_lds_bytes, c->stream, a);
+    else
+        hipLaunchKernelGGL(k_search_fast<8>, dim3(nblocks), dim3(64), L.fast_lds_bytes, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    return BBME_OK;
+}
+
 int launch_search(bbme_ctx *c, int level)
 {
     Level &L = c->lv[level];
+    if (L.fast && !c->force_generic_search) return launch_search_fast(c, level);
     SearchArgs a{};
     a.image1 = L.img1; a.image2 = L.img2;
     a.width = L.width; a.height = L.height;
@@ -121,20 +161,17 @@ int launch_search(bbme_ctx *c, int level)
 }
 
 template <int BS>
-void launch_sweep_t(const RegArgs &a0, int fix_passes, hipStream_t s)
+void launch_sweep_t(const RegArgs &a0, int solve_wgs, hipStream_t s)
 {
     constexpr int LPB = RegCfg<BS>::LPB;
     RegArgs a = a0;
-    const long long threads = (long long)a.rows * a.cols * LPB;
-    const int grid = (int)((threads + 255) / 256);
-    hipLaunchKernelGGL(k_reg_pass1<BS>, dim3(grid), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_reg_pass2<BS>, dim3(grid), dim3(256), 0, s, a);
-    int p = 3;
-    for (int f = 0; f < fix_passes; ++f, ++p) {
-        a.pass = p;
-        hipLaunchKernelGGL(k_reg_fix<BS>, dim3(std::min(grid, 128)), dim3(256), 0, s, a);
-    }
-    a.pass = p;
+    const long long blocks = (long long)a.rows * a.cols;
+    const int grid1 = (int)((blocks * LPB + 255) / 256);
+    const int grid2 = (int)((blocks + 255) / 256);
+    hipLaunchKernelGGL(k_reg_pass1<BS>, dim3(grid1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_reg_detect, dim3(grid2), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_reg_solve<BS>, dim3(solve_wgs), dim3(256), 0, s, a);
+    a.pass = 4;          // reads list0 / counters[1] = the overflow list of k_reg_solve
     hipLaunchKernelGGL(k_reg_tail<BS>, dim3(1), dim3(1024), 0, s, a);
 }
 
@@ -162,15 +199,15 @@ int launch_sweep(bbme_ctx *c, int level, int b, int mult)
     for (int s = L.block; s > b; s >>= 1) lambda = lambda * 2;
     a.lambda_mult = lambda * (float)mult;
     a.list0 = c->list[0]; a.list1 = c->list[1];
-    a.bits0 = c->bits[0]; a.bits1 = c->bits[1];
+    a.qbits = c->qbits;
     a.counters = c->counters;
     switch (b) {
-    case 2:  launch_sweep_t<2>(a, c->fix_passes, c->stream); break;
-    case 4:  launch_sweep_t<4>(a, c->fix_passes, c->stream); break;
-    case 8:  launch_sweep_t<8>(a, c->fix_passes, c->stream); break;
-    case 16: launch_sweep_t<16>(a, c->fix_passes, c->stream); break;
-    case 32: launch_sweep_t<32>(a, c->fix_passes, c->stream); break;
-    case 64: launch_sweep_t<64>(a, c->fix_passes, c->stream); break;
+    case 2:  launch_sweep_t<2>(a, c->solve_wgs, c->stream); break;
+    case 4:  launch_sweep_t<4>(a, c->solve_wgs, c->stream); break;
+    case 8:  launch_sweep_t<8>(a, c->solve_wgs, c->stream); break;
+    case 16: launch_sweep_t<16>(a, c->solve_wgs, c->stream); break;
+    case 32: launch_sweep_t<32>(a, c->solve_wgs, c->stream); break;
+    case 64: launch_sweep_t<64>(a, c->solve_wgs, c->stream); break;
     default: return bbme::fail(BBME_ERR_UNSUPPORTED, "block size %d", b);
     }
     HIP_TRY(hipGetLastError());
@@ -277,8 +314,9 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
 
     bbme_ctx *c = new bbme_ctx();
     c->params = *params; c->geom = g; c->device = device;
-    if (const char *e = getenv("BBME_FIX_PASSES")) c->fix_passes = std::max(0, std::min(16, atoi(e)));
+    if (const char *e = getenv("BBME_SOLVE_WGS")) c->solve_wgs = std::max(1, std::min(2048, atoi(e)));
     if (const char *e = getenv("BBME_NO_GRAPH")) c->use_graph = atoi(e) == 0;
+    if (const char *e = getenv("BBME_GENERIC_SEARCH")) c->force_generic_search = atoi(e) != 0;
     c->lv.resize(nl);
     auto cleanup_fail = [&](int rc) { bbme_destroy(c); return rc; };
     hipError_t err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -306,20 +344,34 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
             (err = hipMemset(L.img1, 0, plane)) != hipSuccess || (err = hipMemset(L.img2, 0, plane)) != hipSuccess ||
             (err = hipMemcpy(L.spiral, packed.data(), packed.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
             return cleanup_fail(bbme::fail(BBME_ERR_HIP, "allocating level %d: %s", l, hipGetErrorString(err)));
+        if (L.block == 8 || L.block == 16) {
+            // the strip kernel reads rank rows dy0 .. dy0+S-1 as 4 x u16 per column group
+            SearchPlan plan = plan_search(L.range, L.block, 16);
+            L.fast = true;
+            L.rank_pitch = sp.rank_pitch;
+            L.nrounds = (int)plan.rounds.size();
+            L.fast_pitch_dw = plan.pitch_dw;
+            L.fast_lds_bytes = (size_t)(L.block + 2 * L.range) * plan.pitch_dw * 4;
+            if ((err = hipMalloc(&L.rank_of, sp.rank_of.size() * 2 + 64)) != hipSuccess ||
+                (err = hipMalloc(&L.tasks, plan.tasks.size() * 4)) != hipSuccess ||
+                (err = hipMalloc(&L.rounds, plan.rounds.size() * 4)) != hipSuccess ||
+                (err = hipMemcpy(L.rank_of, sp.rank_of.data(), sp.rank_of.size() * 2, hipMemcpyHostToDevice)) != hipSuccess ||
+                (err = hipMemcpy(L.tasks, plan.tasks.data(), plan.tasks.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+                (err = hipMemcpy(L.rounds, plan.rounds.data(), plan.rounds.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
+                return cleanup_fail(bbme::fail(BBME_ERR_HIP, "allocating search plan of level %d: %s", l, hipGetErrorString(err)));
+        }
     }
-    const size_t bit_words = (max_blocks + 31) / 32 + 4;
+    const size_t bit_words = (max_blocks + 15) / 16 + 4;
     const size_t flow_bytes = (size_t)g.padded_width * g.padded_height * 2 * sizeof(float);
     const size_t raw_bytes = (size_t)width * height + 64;
     if ((err = hipMalloc(&c->flow, flow_bytes)) != hipSuccess ||
         (err = hipMalloc(&c->list[0], max_blocks * 4)) != hipSuccess ||
         (err = hipMalloc(&c->list[1], max_blocks * 4)) != hipSuccess ||
-        (err = hipMalloc(&c->bits[0], bit_words * 4)) != hipSuccess ||
-        (err = hipMalloc(&c->bits[1], bit_words * 4)) != hipSuccess ||
+        (err = hipMalloc(&c->qbits, bit_words * 4)) != hipSuccess ||
         (err = hipMalloc(&c->counters, 64)) != hipSuccess ||
         (err = hipMalloc(&c->raw[0], raw_bytes)) != hipSuccess ||
         (err = hipMalloc(&c->raw[1], raw_bytes)) != hipSuccess ||
-        (err = hipMemset(c->bits[0], 0, bit_words * 4)) != hipSuccess ||
-        (err = hipMemset(c->bits[1], 0, bit_words * 4)) != hipSuccess ||
+        (err = hipMemset(c->qbits, 0, bit_words * 4)) != hipSuccess ||
         (err = hipMemset(c->counters, 0, 64)) != hipSuccess ||
         (err = hipMemset(c->flow, 0, flow_bytes)) != hipSuccess)
         return cleanup_fail(bbme::fail(BBME_ERR_HIP, "allocating work buffers: %s", hipGetErrorString(err)));
@@ -338,10 +390,11 @@ int bbme_destroy(bbme_ctx *c)
     for (Level &L : c->lv) {
         (void)hipFree(L.img1); (void)hipFree(L.img2);
         (void)hipFree(L.grid[0]); (void)hipFree(L.grid[1]); (void)hipFree(L.spiral);
+        (void)hipFree(L.rank_of); (void)hipFree(L.tasks); (void)hipFree(L.rounds);
     }
     (void)hipFree(c->flow);
     (void)hipFree(c->list[0]); (void)hipFree(c->list[1]);
-    (void)hipFree(c->bits[0]); (void)hipFree(c->bits[1]);
+    (void)hipFree(c->qbits);
     (void)hipFree(c->counters);
     (void)hipFree(c->raw[0]); (void)hipFree(c->raw[1]);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);

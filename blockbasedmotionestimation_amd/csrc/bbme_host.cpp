@@ -214,6 +214,50 @@ SpiralTable build_spiral(int search_size, int block_size)
 }
 
 // ---------------------------------------------------------------------------------------
+// Work split of k_search_fast.  Every (column group, candidate row) pair must be covered exactly
+// once.  A round costs its strip height whatever the number of busy lanes, so rounds are kept
+// full: take the tallest strip height that still has 64 strips available; what is left (< 64
+// single rows) goes into one last round of height 1.
+// ---------------------------------------------------------------------------------------
+SearchPlan plan_search(int range, int block_size, int max_strip)
+{
+    SearchPlan p;
+    const int n = 2 * range + 1;
+    p.groups = (n + 3) / 4;
+    p.pitch_dw = (p.groups + block_size / 4) | 1;
+    std::vector<int> next(p.groups, 0);                      // first uncovered candidate row per column group
+    auto emit_round = [&](int s, int want) {
+        p.rounds.push_back((uint32_t)s);
+        std::vector<uint32_t> t;
+        // strips row by row of columns: lane = strip_row * groups + g keeps a round's LDS reads spread
+        bool more = true;
+        while (more && (int)t.size() < want) {
+            more = false;
+            for (int g = 0; g < p.groups && (int)t.size() < want; ++g)
+                if (n - next[g] >= s) {
+                    t.push_back((uint32_t)g | ((uint32_t)next[g] << 8));
+                    next[g] += s;
+                    more = true;
+                }
+        }
+        t.resize(64, 0xffffffffu);
+        p.tasks.insert(p.tasks.end(), t.begin(), t.end());
+    };
+    for (int s = max_strip; s >= 1; s >>= 1) {
+        for (;;) {
+            int avail = 0;
+            for (int g = 0; g < p.groups; ++g) avail += (n - next[g]) / s;
+            if (avail >= 64) emit_round(s, 64);
+            else break;
+        }
+    }
+    int left = 0;
+    for (int g = 0; g < p.groups; ++g) left += n - next[g];
+    if (left > 0) emit_round(1, left);
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------
 // Flow::ReadFlowFile / WriteFlowFile / CalculateMSE (rw_flow.cpp)
 // ---------------------------------------------------------------------------------------
 static const float kTagFloat = 202021.25f;      // rw_flow.cpp:25

@@ -35,6 +35,16 @@ struct SpiralTable {
 };
 SpiralTable build_spiral(int search_size, int block_size);
 
+// Work split of the fast search kernel: the (2R+1)^2 candidate square as column groups of 4 dx
+// times vertical strips, packed into rounds of up to 64 strips of equal height.
+struct SearchPlan {
+    std::vector<uint32_t> rounds;          // strip height S of each round (16, 8, 4, 2 or 1)
+    std::vector<uint32_t> tasks;           // rounds.size() * 64: g | dy0 << 8, 0xffffffff = idle lane
+    int groups = 0;                        // column groups = ceil((2R+1) / 4)
+    int pitch_dw = 0;                      // LDS window pitch in dwords (odd, >= groups + B/4)
+};
+SearchPlan plan_search(int range, int block_size, int max_strip);
+
 // ---- Flow (rw_flow.cpp) ---------------------------------------------------------------
 int flo_read(const char *filename, int *width, int *height, float **data);
 int flo_write(const char *filename, int width, int height, const float *data);

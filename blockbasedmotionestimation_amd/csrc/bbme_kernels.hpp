@@ -125,6 +125,191 @@ __global__ __launch_bounds__(64) void k_search_generic(SearchArgs a)
 }
 
 // =======================================================================================
+// K1 (fast form, B = 8 or 16): same function, same results, built around v_qsad_pk_u16_u8.
+//
+// One wavefront per macroblock.  The (B+2R)^2 window of image2 is staged in LDS re-aligned so
+// that candidate column dx = -R starts on a dword; the BxB block of image1 sits in SGPRs (its
+// address is wave-uniform).  Candidates are handled four at a time: a "column group" g covers
+// dx indices 4g..4g+3, and one v_qsad_pk_u16_u8 adds |cur dword - window bytes| for all four
+// byte shifts to four packed u16 sums (255 * 16 * 16 < 2^16, so the sums never carry).  A lane
+// owns one column group and a vertical STRIP of S consecutive candidate rows, so each window
+// row it reads from LDS (B/4 + 1 dwords) feeds up to S * B/4 QSADs.  The odd (2R+1)^2 candidate
+// square is cut by the host into "rounds" of up to 64 equal-height strips (S in 16,8,4,2,1) so
+// that lanes stay busy; `tasks` holds (g | dy0 << 8) per lane and round.
+// Winner = min over (SAD << 16) | spiral_rank, i.e. lowest SAD, ties by the reference's visiting
+// order (motion_framework.cpp:326-411, strict < at :339); the rank of every (dx, dy) comes from a
+// table the host builds by walking that loop.  Candidates whose block leaves the image (:335) and
+// the padding columns of the last group get SAD 0xffff and can never win (the centre is valid).
+// LDS pitch is an odd number of dwords: the four strips of a full round then hit disjoint banks.
+// =======================================================================================
+struct FastSearchArgs {
+    const uint8_t *image1, *image2;
+    int width, height;
+    int range;                  // R
+    const uint32_t *spiral;     // rank -> (dx & 0xffff) | (dy << 16)
+    const uint16_t *rank_of;    // [(dy+R) * rank_pitch + (dx+R)] -> rank, 0xffff where dx > R
+    int rank_pitch;             // multiple of 4
+    const uint32_t *tasks;      // nrounds * 64 entries: g | dy0 << 8, 0xffffffff = idle lane
+    const uint32_t *rounds;     // nrounds entries: strip height S
+    int nrounds;
+    const mv_t *coarse;
+    int coarse_cols, coarse_block;
+    mv_t *out;
+    int cols;
+    int pitch_dw;               // LDS window pitch in dwords (odd)
+};
+
+template <int B, int S>
+__device__ __forceinline__ uint32_t search_strip(const uint32_t *win, int P, const uint32_t (&cur)[B][B / 4],
+                                                 uint32_t task, const FastSearchArgs &a, uint32_t best,
+                                                 bool border, int xlo, int xhi, int ylo, int yhi)
+{
+    constexpr int BW = B / 4;
+    const bool idle = task == 0xffffffffu;
+    const int g = idle ? 0 : (int)(task & 0xffu);
+    const int dy0 = idle ? 0 : (int)((task >> 8) & 0xffu);
+    unsigned long long acc[S];
+#pragma unroll
+    for (int d = 0; d < S; ++d) acc[d] = 0;
+    // One window row ahead is kept in flight.  The QSAD chains are pure, so the optimiser would
+    // sink all of them below all of the LDS reads (150+ live VGPRs, occupancy gone); the empty asm
+    // statements pin the order: reads of row yy+1, then the QSADs of row yy, row after row.
+    const uint32_t *wrow = win + dy0 * P + g;
+    uint32_t wn[BW + 1];
+#pragma unroll
+    for (int q = 0; q <= BW; ++q) wn[q] = wrow[q];
+    wrow += P;
+#pragma unroll
+    for (int yy = 0; yy < B + S - 1; ++yy) {
+        uint32_t w[BW + 1];
+#pragma unroll
+        for (int q = 0; q <= BW; ++q) w[q] = wn[q];
+        if (yy + 1 < B + S - 1) {
+#pragma unroll
+            for (int q = 0; q <= BW; ++q) wn[q] = wrow[q];
+            wrow += P;
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int d = 0; d < S; ++d) {
+            const int brow = yy - d;                       // row of the current block this window row meets
+            if (brow < 0 || brow >= B) continue;
+#pragma unroll
+            for (int q = 0; q < BW; ++q) {
+                const unsigned long long pair = ((unsigned long long)w[q + 1] << 32) | w[q];
+                acc[d] = __builtin_amdgcn_qsad_pk_u16_u8(pair, cur[brow][q], acc[d]);
+            }
+            asm volatile("" : "+v"(acc[d]));
+        }
+    }
+    // column validity: padding columns of the last group, and (near the image border) blocks leaving the image
+    unsigned long long colmask = idle ? ~0ull : 0ull;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int dxi = 4 * g + c;
+        if (dxi > 2 * a.range || (border && (dxi < xlo || dxi > xhi))) colmask |= 0xffffull << (16 * c);
+    }
+    const uint16_t *rk = a.rank_of + (size_t)dy0 * a.rank_pitch + 4 * g;
+#pragma unroll
+    for (int d = 0; d < S; ++d) {
+        unsigned long long v = acc[d] | colmask;
+        if (border && (dy0 + d < ylo || dy0 + d > yhi)) v = ~0ull;
+        const uint2 r4 = *reinterpret_cast<const uint2 *>(rk);
+        rk += a.rank_pitch;
+        const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+        // key = (sad << 16) | rank, assembled bytewise: v_perm_b32(S0 = sums, S1 = ranks)
+        const uint32_t k0 = __builtin_amdgcn_perm(lo, r4.x, 0x05040100u);
+        const uint32_t k1 = __builtin_amdgcn_perm(lo, r4.x, 0x07060302u);
+        const uint32_t k2 = __builtin_amdgcn_perm(hi, r4.y, 0x05040100u);
+        const uint32_t k3 = __builtin_amdgcn_perm(hi, r4.y, 0x07060302u);
+        best = min(best, min(min(k0, k1), min(k2, k3)));
+    }
+    return best;
+}
+
+template <int B>
+__global__ __launch_bounds__(64) void k_search_fast(FastSearchArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    constexpr int BW = B / 4;
+    const int lane = threadIdx.x;
+    const int bc = blockIdx.x % a.cols, br = blockIdx.x / a.cols;
+    const int i = br * B, j = bc * B;
+
+    int u = 0, v = 0;                                       // copyMVs (:828-843)
+    if (a.coarse) {
+        const int ci = (i / (2 * a.coarse_block)) * a.coarse_block;
+        const int cj = (j / (2 * a.coarse_block)) * a.coarse_block;
+        const mv_t m = a.coarse[(size_t)(ci >> 1) * a.coarse_cols + (cj >> 1)];
+        u = 2 * mv_x(m); v = 2 * mv_y(m);
+    }
+    const int px = j + u, py = i + v;                       // :233-234
+    mv_t *dst = a.out + (size_t)br * a.cols + bc;
+    if (px < 0 || py < 0 || px + B > a.width || py + B > a.height) {    // :304-310
+        if (lane == 0) *dst = 0;
+        return;
+    }
+    const int R = a.range, P = a.pitch_dw;
+    const int wrows = B + 2 * R;
+    const int wx0 = px - R, wy0 = py - R;
+    const int ax0 = wx0 & ~3, sh0 = wx0 & 3;
+
+    // stage the window: lane (rr, k) produces dword k of rows rr, rr + RPI, ... re-aligned by sh0 bytes
+    {
+        const int rpi = 64 / P;                              // rows per pass
+        const int rr = lane / P, k = lane - rr * P;
+        if (rr < rpi) {
+            const int x = ax0 + 4 * k;
+            const bool x_lo_ok = x >= 0 && x + 4 <= a.width;
+            const bool x_hi_ok = sh0 != 0 && x + 4 >= 0 && x + 8 <= a.width;
+            for (int row = rr; row < wrows; row += rpi) {
+                const int y = wy0 + row;
+                uint32_t lo = 0, hi = 0;
+                if (y >= 0 && y < a.height) {
+                    const uint8_t *src = a.image2 + (size_t)y * a.width + x;
+                    if (x_lo_ok) lo = *reinterpret_cast<const uint32_t *>(src);
+                    if (x_hi_ok) hi = *reinterpret_cast<const uint32_t *>(src + 4);
+                }
+                smem[row * P + k] = __builtin_amdgcn_alignbyte(hi, lo, sh0);
+            }
+        }
+    }
+    // the current block: wave-uniform addresses -> scalar loads, lives in SGPRs
+    uint32_t cur[B][BW];
+#pragma unroll
+    for (int r = 0; r < B; ++r) {
+        const uint32_t *c1 = reinterpret_cast<const uint32_t *>(a.image1 + (size_t)(i + r) * a.width + j);
+#pragma unroll
+        for (int q = 0; q < BW; ++q) cur[r][q] = __builtin_amdgcn_readfirstlane(c1[q]);
+    }
+    __syncthreads();
+
+    // candidate (dxi, dyi) in [0, 2R]^2 is valid iff its block lies inside the image (:335)
+    const bool border = wx0 < 0 || wy0 < 0 || wx0 + wrows > a.width || wy0 + wrows > a.height;
+    const int xlo = max(0, -wx0), xhi = min(2 * R, a.width - B - wx0);
+    const int ylo = max(0, -wy0), yhi = min(2 * R, a.height - B - wy0);
+
+    uint32_t best = 0xffffffffu;
+    for (int rd = 0; rd < a.nrounds; ++rd) {
+        const uint32_t S = a.rounds[rd];
+        const uint32_t task = a.tasks[rd * 64 + lane];
+        switch (S) {
+        case 16: best = search_strip<B, 16>(smem, P, cur, task, a, best, border, xlo, xhi, ylo, yhi); break;
+        case 8:  best = search_strip<B, 8>(smem, P, cur, task, a, best, border, xlo, xhi, ylo, yhi); break;
+        case 4:  best = search_strip<B, 4>(smem, P, cur, task, a, best, border, xlo, xhi, ylo, yhi); break;
+        case 2:  best = search_strip<B, 2>(smem, P, cur, task, a, best, border, xlo, xhi, ylo, yhi); break;
+        default: best = search_strip<B, 1>(smem, P, cur, task, a, best, border, xlo, xhi, ylo, yhi); break;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o));
+    if (lane == 0) {
+        const uint32_t sp = a.spiral[best & 0xffffu];
+        *dst = mv_pack(u + (int)(int16_t)(sp & 0xffffu), v + (int)(int16_t)(sp >> 16));   // :238-239
+    }
+}
+
+// =======================================================================================
 // K2: MF::regularize_MVs / find_min_candidate / calculate_smoothness / min_energy_candidate
 // (motion_framework.cpp:424-662), solved as a fixed point instead of an in-place raster sweep.
 //
@@ -133,11 +318,10 @@ __global__ __launch_bounds__(64) void k_search_generic(SearchArgs a)
 // and its right / lower neighbours.  The dependency graph of `new` is acyclic, so the field
 // is the unique fixed point of that system.  We reach it by:
 //   pass 1   every block evaluated with new := old                          (k_reg_pass1)
-//   pass 2   every block whose L/UL/U/UR changed in pass 1 is re-evaluated  (k_reg_pass2)
-//   pass k   blocks pushed onto a work list by a changed neighbour          (k_reg_fix, k_reg_tail)
-// until a pass changes nothing.  A block that changes pushes R, DR, D, DL (its dependants).
-// k_reg_tail is a single workgroup that loops to convergence, so the launch sequence is
-// fixed and needs no host synchronisation.  Energies are float32 exactly as the reference's
+//   detect   every block whose L/UL/U/UR changed in pass 1 is queued        (k_reg_detect)
+//   solve    queued blocks are re-evaluated; a block that changes queues R, DR, D, DL (its
+//            dependants) -- asynchronously, each wave following its own chains (k_reg_solve)
+// until no block is queued.  The launch sequence is fixed and needs no host synchronisation.  Energies are float32 exactly as the reference's
 // (SAD + lambda * mult * Smoothness, FLT_MAX for out-of-image candidates, first strict min).
 //
 // BS x BS blocks; LPB lanes cooperate on one block, one image row per lane.
@@ -153,10 +337,10 @@ struct RegArgs {
     float lambda_mult;          // lambda * (float)lambda_multiplier, computed as the reference does
     // work lists
     uint32_t *list0, *list1;    // block indices
-    uint32_t *bits0, *bits1;    // "already queued" bitmaps, one per list
+    uint32_t *qbits;            // QUEUED / BUSY bits, two per block (see "work-list state" below)
     uint32_t *counters;         // [0..2] list lengths (rotating), [3] passes run, [4] blocks re-evaluated,
                                 // [5] sticky: a sweep hit the pass cap without converging
-    int pass;                   // pass number of this launch (k_reg_fix) / first pass (k_reg_tail)
+    int pass;                   // first pass number of k_reg_tail
 };
 
 template <int BS> struct RegCfg {
@@ -279,28 +463,28 @@ __device__ __forceinline__ mv_t eval_block(const RegArgs &a, int r, int c, int s
     return res;
 }
 
-// dependants of block x = (r, c): R, DR, D, DL.  Queue them (once) on the next list.
-__device__ __forceinline__ void push_dependants(const RegArgs &a, int r, int c,
-                                                uint32_t *list, uint32_t *bits, uint32_t *count)
-{
-    const int dr[4] = {0, 1, 1, 1}, dc[4] = {1, 1, 0, -1};
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        const int rr = r + dr[d], cc = c + dc[d];
-        if (rr < 0 || rr >= a.rows || cc < 0 || cc >= a.cols) continue;
-        const uint32_t x = (uint32_t)rr * a.cols + cc;
-        const uint32_t bit = 1u << (x & 31);
-        if (!(atomicOr(&bits[x >> 5], bit) & bit))
-            list[atomicAdd(count, 1u)] = x;
-    }
-}
+// ---- work-list state ---------------------------------------------------------------------
+// Two bits per block in `qbits` (16 blocks per word):
+//   QUEUED  the block sits in exactly one queue (a wave's LDS queue or a global list);
+//   BUSY    one wave is evaluating it right now.
+// Rules (every access is an agent-scope atomic, so they hold across XCDs):
+//   pop    QUEUED -> 0 (and BUSY -> 1 in k_reg_solve), COMPLETED before any input is loaded, so a
+//          change that lands after the loads finds QUEUED clear and queues the block again;
+//   push   after the changed estimate has been stored AND that store has completed: set QUEUED;
+//          the pusher enqueues the block only if neither bit was set before -- if BUSY was set,
+//          the evaluating wave re-queues it itself when it clears BUSY and finds QUEUED set.
+// Hence no block is ever evaluated by two waves at once, and every block whose inputs changed
+// after its last evaluation is queued: when all queues are empty the field is the fixed point.
+__device__ __forceinline__ uint32_t q_bit(uint32_t x) { return 1u << (2 * (x & 15)); }
+__device__ __forceinline__ uint32_t b_bit(uint32_t x) { return 2u << (2 * (x & 15)); }
+#define BBME_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
 template <int BS>
 __global__ __launch_bounds__(256) void k_reg_pass1(RegArgs a)
 {
     constexpr int LPB = RegCfg<BS>::LPB;
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t == 0) { a.counters[0] = 0; a.counters[1] = 0; a.counters[2] = 0; a.counters[3] = 1; a.counters[4] = 0; }
+    if (t == 0) { a.counters[0] = 0; a.counters[1] = 0; a.counters[2] = 0; a.counters[3] = 0; a.counters[4] = 0; }
     const long long g = t / LPB;
     const int sub = (int)(t % LPB);
     if (g >= (long long)a.rows * a.cols) return;   // whole groups drop out together (LPB | 256)
@@ -309,18 +493,14 @@ __global__ __launch_bounds__(256) void k_reg_pass1(RegArgs a)
     if (sub == 0) a.est[g] = res;
 }
 
-// pass 2: pull form.  A block is re-evaluated iff one of its already-updated inputs differs
-// from the old value pass 1 assumed.  Changes are written in place and push dependants for
-// pass 3 (list1 / bits1 / counters[0]).
-template <int BS>
-__global__ __launch_bounds__(256) void k_reg_pass2(RegArgs a)
+// pass 2, pull form, detection only: a block must be re-evaluated iff one of its already-updated
+// inputs (L, UL, U, UR) came out of pass 1 different from the old value pass 1 assumed for it.
+// Such blocks are queued on list1 (length counters[0]).  One thread per block.
+__global__ __launch_bounds__(256) void k_reg_detect(RegArgs a)
 {
-    constexpr int LPB = RegCfg<BS>::LPB;
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long g = t / LPB;
-    const int sub = (int)(t % LPB);
-    if (g >= (long long)a.rows * a.cols) return;
-    const int r = (int)(g / a.cols), c = (int)(g % a.cols);
+    const long long x = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (x >= (long long)a.rows * a.cols) return;
+    const int r = (int)(x / a.cols), c = (int)(x % a.cols);
     bool stale = false;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
@@ -331,70 +511,116 @@ __global__ __launch_bounds__(256) void k_reg_pass2(RegArgs a)
         const mv_t o = a.old_grid[(size_t)(rr >> a.old_shift) * a.old_cols + (cc >> a.old_shift)];
         stale |= (e != o);
     }
-    if (!stale) return;                              // uniform within the group
-    const mv_t res = eval_block<BS, false>(a, r, c, sub, BBME_NEW_MASK);
-    if (sub == 0) {
-        atomicAdd(&a.counters[4], 1u);
-        if (res != a.est[g]) {
-            a.est[g] = res;
-            push_dependants(a, r, c, a.list1, a.bits1, &a.counters[0]);
-        }
+    if (stale) {
+        atomicOr(&a.qbits[x >> 4], q_bit((uint32_t)x));
+        a.list1[atomicAdd(&a.counters[0], 1u)] = (uint32_t)x;
     }
 }
 
-// one work-list pass; pass number p reads list[p&1] (length counters[p%3]), appends to
-// list[(p+1)&1] (counters[(p+1)%3]) and zeroes counters[(p+2)%3] for the pass after.
-template <int BS, bool COHERENT>
-__device__ __forceinline__ void worklist_pass(const RegArgs &a, int p, uint32_t n,
-                                              int group, int ngroups, int sub)
-{
-    const uint32_t *lcur = (p & 1) ? a.list1 : a.list0;
-    uint32_t *bcur = (p & 1) ? a.bits1 : a.bits0;
-    uint32_t *lnext = (p & 1) ? a.list0 : a.list1;
-    uint32_t *bnext = (p & 1) ? a.bits0 : a.bits1;
-    uint32_t *cnext = &a.counters[(p + 1) % 3];
-    for (uint32_t idx = group; idx < n; idx += ngroups) {
-        const uint32_t x = COHERENT ? __hip_atomic_load(&lcur[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                    : lcur[idx];
-        const int r = (int)(x / a.cols), c = (int)(x % a.cols);
-        if (sub == 0) atomicAnd(&bcur[x >> 5], ~(1u << (x & 31)));
-        const mv_t res = eval_block<BS, COHERENT>(a, r, c, sub, BBME_NEW_MASK);
-        if (sub == 0) {
-            const mv_t prev = load_est<COHERENT>(a.est + x);
-            if (res != prev) {
-                if constexpr (COHERENT)
-                    __hip_atomic_store(a.est + x, res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else
-                    a.est[x] = res;
-                push_dependants(a, r, c, lnext, bnext, cnext);
-            }
-        }
-    }
-}
-
+// Asynchronous solver.  Every wave owns a private LDS queue.  It takes chunks of the global list,
+// and whatever its own changes make stale it queues locally and evaluates itself, round after
+// round, without any grid-wide step: fixed-point iteration tolerates any evaluation order.  A wave
+// whose queue is empty and which has no chunk left simply exits.  If a local queue is full the
+// surplus goes to the overflow list, which k_reg_tail (below) finishes.
 template <int BS>
-__global__ __launch_bounds__(256) void k_reg_fix(RegArgs a)
+__global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
 {
     constexpr int LPB = RegCfg<BS>::LPB;
-    const int p = a.pass;
-    const uint32_t n = a.counters[p % 3];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        a.counters[(p + 2) % 3] = 0;
-        if (n) { a.counters[3] = p; atomicAdd(&a.counters[4], n); }
+    constexpr int NB = 64 / LPB;                 // blocks evaluated per wave per round
+    constexpr uint32_t QCAP = 1024;
+    __shared__ uint32_t qmem[4][QCAP];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    uint32_t *q = qmem[wave];
+    const uint32_t w = blockIdx.x * 4 + wave, W = gridDim.x * 4;
+    const uint32_t n = a.counters[0];
+    const uint32_t *in_list = a.list1;
+    uint32_t *ovf_list = a.list0;
+    uint32_t *ovf_count = &a.counters[1];
+    const int g = lane / LPB, sub = lane % LPB;
+    uint32_t head = 0, tail = 0;                  // wave-uniform, free-running
+    uint32_t evaluated = 0, rounds = 0;
+    // every round either empties part of the queue or follows a real change; the cap is only an
+    // exit that every wave reaches should that reasoning ever be wrong (reported via counters[5])
+    const uint32_t round_cap = 64u * (uint32_t)(2 * a.rows + a.cols + 16);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    // enqueue `flag`ged lanes' value v on the wave's queue (or the overflow list when full)
+    auto enqueue = [&](bool flag, uint32_t v) {
+        const unsigned long long m = __ballot(flag);
+        const uint32_t total = (uint32_t)__popcll(m);
+        if (total == 0) return;
+        if (tail - head + total <= QCAP) {
+            if (flag) q[(tail + (uint32_t)__popcll(m & lt_mask)) % QCAP] = v;
+            tail = __builtin_amdgcn_readfirstlane(tail + total);
+        } else if (flag) {
+            ovf_list[atomicAdd(ovf_count, 1u)] = v;        // stays QUEUED; k_reg_tail takes it
+        }
+    };
+
+    for (uint32_t chunk = w;; chunk += W) {
+        const uint32_t base = chunk * NB;
+        if (base < n) {
+            const uint32_t take = min((uint32_t)NB, n - base);
+            if ((uint32_t)lane < take) q[(tail + lane) % QCAP] = in_list[base + lane];
+            tail = __builtin_amdgcn_readfirstlane(tail + take);
+        } else if (head == tail) {
+            break;
+        }
+        while (head != tail) {
+            if (++rounds > round_cap) { if (lane == 0) a.counters[5] = 1; head = tail; break; }
+            const uint32_t cnt = min((uint32_t)NB, tail - head);
+            const bool active = (uint32_t)g < cnt;
+            const uint32_t x = active ? q[(head + g) % QCAP] : 0u;
+            head = __builtin_amdgcn_readfirstlane(head + cnt);
+            const bool leader = active && sub == 0;
+            if (leader) atomicXor(&a.qbits[x >> 4], q_bit(x) | b_bit(x));      // pop: QUEUED -> 0, BUSY -> 1
+            BBME_DRAIN();
+            bool changed = false;
+            int r = 0, c = 0;
+            if (active) {
+                r = (int)(x / a.cols); c = (int)(x % a.cols);
+                mv_t prev = 0;
+                if (leader) prev = load_est<true>(a.est + x);          // issued with the candidate loads
+                const mv_t res = eval_block<BS, true>(a, r, c, sub, BBME_NEW_MASK);
+                changed = leader && res != prev;
+                if (changed) __hip_atomic_store(a.est + x, res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            evaluated += cnt;
+            if (__ballot(changed)) BBME_DRAIN();                       // the stores have completed
+            // one trip for all five atomics: queue the dependants R, DR, D, DL and clear BUSY
+            const int dr[4] = {0, 1, 1, 1}, dc[4] = {1, 1, 0, -1};
+            uint32_t xd[4], oldw[4];
+            bool want[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int rr = r + dr[d], cc = c + dc[d];
+                want[d] = changed && rr < a.rows && cc >= 0 && cc < a.cols;
+                xd[d] = want[d] ? (uint32_t)rr * a.cols + cc : 0u;
+                oldw[d] = 0;
+                if (want[d]) oldw[d] = atomicOr(&a.qbits[xd[d] >> 4], q_bit(xd[d]));
+            }
+            uint32_t oldx = 0;
+            if (leader) oldx = atomicAnd(&a.qbits[x >> 4], ~b_bit(x));           // BUSY -> 0
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                enqueue(want[d] && !(oldw[d] & (q_bit(xd[d]) | b_bit(xd[d]))), xd[d]);
+            enqueue(leader && (oldx & q_bit(x)) != 0, x);              // queued while we were evaluating it
+        }
     }
-    if (n == 0) return;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    worklist_pass<BS, false>(a, p, n, t / LPB, (int)(gridDim.x * 256) / LPB, t % LPB);
+    if (lane == 0 && evaluated) atomicAdd(&a.counters[4], evaluated);
 }
 
-// Single workgroup, loops over work-list passes until one leaves the next list empty.
-// Visibility between passes: every wave drains its stores (s_waitcnt vmcnt(0)) before the
-// barrier; estimate / list / counter reads in the next pass bypass the L1 (agent-scope loads).
+// Safety net: single workgroup, global lists that cannot overflow (a block is on a list at most once),
+// loops pass by pass until a pass queues nothing.  Pass p reads list[p&1] (length counters[p%3]),
+// appends to list[(p+1)&1] (counters[(p+1)%3]) and zeroes counters[(p+2)%3].  It normally finds the
+// overflow list of k_reg_solve empty and exits at once.
 template <int BS>
 __global__ __launch_bounds__(1024) void k_reg_tail(RegArgs a)
 {
     constexpr int LPB = RegCfg<BS>::LPB;
     const int t = threadIdx.x;
+    const int group = t / LPB, ngroups = 1024 / LPB, sub = t % LPB;
     int p = a.pass;
     // a change can only travel along the raster dependency chain, whose length is below
     // 2*rows + cols; the cap is an exit every wave reaches even if that reasoning were wrong
@@ -402,16 +628,38 @@ __global__ __launch_bounds__(1024) void k_reg_tail(RegArgs a)
     for (;;) {
         const uint32_t n = __hip_atomic_load(&a.counters[p % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (n == 0) break;
-        if (p > p_max) { if (t == 0) a.counters[5] = 1; break; }      // reported by bbme_synchronize
+        if (p > p_max) { if (t == 0) a.counters[5] = 1; break; }      // reported by bbme_last_sweep_passes
         __syncthreads();                              // everyone has read n before it can be reused
         if (t == 0) {
             __hip_atomic_store(&a.counters[(p + 2) % 3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a.counters[3] = p;
+            a.counters[3] += 1;
             a.counters[4] += n;
         }
-        worklist_pass<BS, true>(a, p, n, t / LPB, 1024 / LPB, t % LPB);
+        const uint32_t *lcur = (p & 1) ? a.list1 : a.list0;
+        uint32_t *lnext = (p & 1) ? a.list0 : a.list1;
+        uint32_t *cnext = &a.counters[(p + 1) % 3];
+        for (uint32_t idx = group; idx < n; idx += ngroups) {
+            const uint32_t x = __hip_atomic_load(&lcur[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int r = (int)(x / a.cols), c = (int)(x % a.cols);
+            if (sub == 0) atomicAnd(&a.qbits[x >> 4], ~q_bit(x));                 // pop
+            BBME_DRAIN();
+            const mv_t res = eval_block<BS, true>(a, r, c, sub, BBME_NEW_MASK);
+            if (sub == 0 && res != load_est<true>(a.est + x)) {
+                __hip_atomic_store(a.est + x, res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                BBME_DRAIN();
+                const int dr[4] = {0, 1, 1, 1}, dc[4] = {1, 1, 0, -1};
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int rr = r + dr[d], cc = c + dc[d];
+                    if (rr >= a.rows || cc < 0 || cc >= a.cols) continue;
+                    const uint32_t xd = (uint32_t)rr * a.cols + cc;
+                    if (!(atomicOr(&a.qbits[xd >> 4], q_bit(xd)) & q_bit(xd)))
+                        lnext[atomicAdd(cnext, 1u)] = xd;
+                }
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BBME_DRAIN();
         __syncthreads();
         ++p;
     }
