@@ -76,6 +76,7 @@ SIGNATURES = {
     "bbme_stage_set_mvs": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p]),
     "bbme_stage_expand": (C.c_int, [_ctx]),
     "bbme_last_sweep_passes": (C.c_int, [_ctx, _P(C.c_int)]),
+    "bbme_sweep_stats": (C.c_int, [_ctx, _P(C.c_uint)]),
     "bbme_set_profiling": (C.c_int, [_ctx, C.c_int]),
     "bbme_get_timings": (C.c_int, [_ctx] + [_P(C.c_float)] * 5),
     "bbme_selftest_isa": (C.c_int, [C.c_int, _P(C.c_int)]),

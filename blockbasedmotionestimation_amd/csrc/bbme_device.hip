@@ -55,11 +55,11 @@ struct bbme_ctx {
     std::vector<Level> lv;
     float *flow = nullptr;                        // dense padded H0 x W0 float2
     uint32_t *list[2] = {nullptr, nullptr};
-    uint32_t *qbits = nullptr;                    // QUEUED/BUSY, two bits per block
+    uint32_t *own = nullptr;                      // ownership counters of the solver, 16 bits per block
     uint32_t *counters = nullptr;                 // 8 words
     uint8_t *raw[2] = {nullptr, nullptr};         // unpadded frames for bbme_set_frames_device staging
     bool frames_set = false;
-    int solve_wgs = 256;                          // workgroups of k_reg_solve (4 independent waves each)
+    int solve_wgs = 1280;                         // most workgroups of k_reg_solve (4 independent waves each)
     bool force_generic_search = false;            // BBME_GENERIC_SEARCH=1: use k_search_generic everywhere
     bool use_graph = true;
     hipGraphExec_t graph_exec = nullptr;
@@ -161,18 +161,15 @@ int launch_search(bbme_ctx *c, int level)
 }
 
 template <int BS>
-void launch_sweep_t(const RegArgs &a0, int solve_wgs, hipStream_t s)
+void launch_sweep_t(const RegArgs &a, int max_solve_wgs, hipStream_t s)
 {
     constexpr int LPB = RegCfg<BS>::LPB;
-    RegArgs a = a0;
     const long long blocks = (long long)a.rows * a.cols;
     const int grid1 = (int)((blocks * LPB + 255) / 256);
-    const int grid2 = (int)((blocks + 255) / 256);
+    // every solver wave scans 64 blocks per step; more workgroups than that would find nothing
+    const int grid2 = (int)std::min<long long>(max_solve_wgs, (blocks + 255) / 256);
     hipLaunchKernelGGL(k_reg_pass1<BS>, dim3(grid1), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_reg_detect, dim3(grid2), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_reg_solve<BS>, dim3(solve_wgs), dim3(256), 0, s, a);
-    a.pass = 4;          // reads list0 / counters[1] = the overflow list of k_reg_solve
-    hipLaunchKernelGGL(k_reg_tail<BS>, dim3(1), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(k_reg_solve<BS>, dim3(grid2), dim3(256), 0, s, a);
 }
 
 // One regularize_MVs() sweep at block size b (divide_blocks fused when the grid is at 2b).
@@ -199,7 +196,7 @@ int launch_sweep(bbme_ctx *c, int level, int b, int mult)
     for (int s = L.block; s > b; s >>= 1) lambda = lambda * 2;
     a.lambda_mult = lambda * (float)mult;
     a.list0 = c->list[0]; a.list1 = c->list[1];
-    a.qbits = c->qbits;
+    a.own = c->own;
     a.counters = c->counters;
     switch (b) {
     case 2:  launch_sweep_t<2>(a, c->solve_wgs, c->stream); break;
@@ -314,7 +311,7 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
 
     bbme_ctx *c = new bbme_ctx();
     c->params = *params; c->geom = g; c->device = device;
-    if (const char *e = getenv("BBME_SOLVE_WGS")) c->solve_wgs = std::max(1, std::min(2048, atoi(e)));
+    if (const char *e = getenv("BBME_SOLVE_WGS")) c->solve_wgs = std::max(1, std::min(8192, atoi(e)));
     if (const char *e = getenv("BBME_NO_GRAPH")) c->use_graph = atoi(e) == 0;
     if (const char *e = getenv("BBME_GENERIC_SEARCH")) c->force_generic_search = atoi(e) != 0;
     c->lv.resize(nl);
@@ -361,17 +358,17 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
                 return cleanup_fail(bbme::fail(BBME_ERR_HIP, "allocating search plan of level %d: %s", l, hipGetErrorString(err)));
         }
     }
-    const size_t bit_words = (max_blocks + 15) / 16 + 4;
+    const size_t bit_words = (max_blocks + 1) / 2 + 4;
     const size_t flow_bytes = (size_t)g.padded_width * g.padded_height * 2 * sizeof(float);
     const size_t raw_bytes = (size_t)width * height + 64;
     if ((err = hipMalloc(&c->flow, flow_bytes)) != hipSuccess ||
         (err = hipMalloc(&c->list[0], max_blocks * 4)) != hipSuccess ||
         (err = hipMalloc(&c->list[1], max_blocks * 4)) != hipSuccess ||
-        (err = hipMalloc(&c->qbits, bit_words * 4)) != hipSuccess ||
+        (err = hipMalloc(&c->own, bit_words * 4)) != hipSuccess ||
         (err = hipMalloc(&c->counters, 64)) != hipSuccess ||
         (err = hipMalloc(&c->raw[0], raw_bytes)) != hipSuccess ||
         (err = hipMalloc(&c->raw[1], raw_bytes)) != hipSuccess ||
-        (err = hipMemset(c->qbits, 0, bit_words * 4)) != hipSuccess ||
+        (err = hipMemset(c->own, 0, bit_words * 4)) != hipSuccess ||
         (err = hipMemset(c->counters, 0, 64)) != hipSuccess ||
         (err = hipMemset(c->flow, 0, flow_bytes)) != hipSuccess)
         return cleanup_fail(bbme::fail(BBME_ERR_HIP, "allocating work buffers: %s", hipGetErrorString(err)));
@@ -394,7 +391,7 @@ int bbme_destroy(bbme_ctx *c)
     }
     (void)hipFree(c->flow);
     (void)hipFree(c->list[0]); (void)hipFree(c->list[1]);
-    (void)hipFree(c->qbits);
+    (void)hipFree(c->own);
     (void)hipFree(c->counters);
     (void)hipFree(c->raw[0]); (void)hipFree(c->raw[1]);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -664,6 +661,16 @@ int bbme_last_sweep_passes(bbme_ctx *c, int *passes)
     passes[0] = (int)host[3];
     passes[1] = (int)host[4];
     if (host[5]) return bbme::fail(BBME_ERR_STATE, "a regulariser sweep hit its pass cap without converging");
+    return BBME_OK;
+}
+
+int bbme_sweep_stats(bbme_ctx *c, unsigned *stats)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (!stats) return bbme::fail(BBME_ERR_INVALID, "null output");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(stats, c->counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return BBME_OK;
 }
 

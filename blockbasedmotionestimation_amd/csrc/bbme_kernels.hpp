@@ -318,10 +318,10 @@ __global__ __launch_bounds__(64) void k_search_fast(FastSearchArgs a)
 // and its right / lower neighbours.  The dependency graph of `new` is acyclic, so the field
 // is the unique fixed point of that system.  We reach it by:
 //   pass 1   every block evaluated with new := old                          (k_reg_pass1)
-//   detect   every block whose L/UL/U/UR changed in pass 1 is queued        (k_reg_detect)
-//   solve    queued blocks are re-evaluated; a block that changes queues R, DR, D, DL (its
-//            dependants) -- asynchronously, each wave following its own chains (k_reg_solve)
-// until no block is queued.  The launch sequence is fixed and needs no host synchronisation.  Energies are float32 exactly as the reference's
+//   solve    every block whose L/UL/U/UR changed in pass 1 is queued and re-evaluated; a block
+//            that changes claims R, DR, D, DL (its dependants) -- asynchronously, each wave
+//            following its own chains                                       (k_reg_solve)
+// until no block is queued.  Two launches per sweep, no host synchronisation.  Energies are float32 exactly as the reference's
 // (SAD + lambda * mult * Smoothness, FLT_MAX for out-of-image candidates, first strict min).
 //
 // BS x BS blocks; LPB lanes cooperate on one block, one image row per lane.
@@ -337,10 +337,9 @@ struct RegArgs {
     float lambda_mult;          // lambda * (float)lambda_multiplier, computed as the reference does
     // work lists
     uint32_t *list0, *list1;    // block indices
-    uint32_t *qbits;            // QUEUED / BUSY bits, two per block (see "work-list state" below)
-    uint32_t *counters;         // [0..2] list lengths (rotating), [3] passes run, [4] blocks re-evaluated,
-                                // [5] sticky: a sweep hit the pass cap without converging
-    int pass;                   // first pass number of k_reg_tail
+    uint32_t *own;              // ownership counters, 16 bits per block (see "work-list state" below)
+    uint32_t *counters;         // [0..2] list lengths (rotating), [3] safety-net passes, [4] blocks re-evaluated,
+                                // [5] sticky: a sweep hit a cap without converging, [6] solver ticket
 };
 
 template <int BS> struct RegCfg {
@@ -363,73 +362,92 @@ __device__ __forceinline__ mv_t load_est(const mv_t *p)
         return *p;
 }
 
-// SAD of one BS-pixel row: image1 at (bx, y1) [aligned], image2 at (x2, y2) [any alignment].
-template <int BS>
-__device__ __forceinline__ uint32_t row_sad(const RegArgs &a, int bx, int y1, int x2, int y2)
-{
-    if constexpr (BS >= 4) {
-        constexpr int NW = BS / 4;
-        const uint32_t *p1 = reinterpret_cast<const uint32_t *>(a.image1 + (size_t)y1 * a.width + bx);
-        const int ax = x2 & ~3, sh = x2 & 3;
-        const uint32_t *p2 = reinterpret_cast<const uint32_t *>(a.image2 + (size_t)y2 * a.width + ax);
-        // the dword after the last one is only needed when sh != 0, and then it lies inside the row
-        uint32_t w[NW + 1];
-#pragma unroll
-        for (int q = 0; q < NW; ++q) w[q] = p2[q];
-        w[NW] = sh ? p2[NW] : 0u;
-        uint32_t sad = 0;
-#pragma unroll
-        for (int q = 0; q < NW; ++q)
-            sad = __builtin_amdgcn_sad_u8(p1[q], __builtin_amdgcn_alignbyte(w[q + 1], w[q], sh), sad);
-        return sad;
-    } else {   // BS == 2: two pixels
-        const uint8_t *p1 = a.image1 + (size_t)y1 * a.width + bx;
-        const uint8_t *p2 = a.image2 + (size_t)y2 * a.width + x2;
-        const uint32_t v1 = (uint32_t)p1[0] | ((uint32_t)p1[1] << 8);
-        const uint32_t v2 = (uint32_t)p2[0] | ((uint32_t)p2[1] << 8);
-        return __builtin_amdgcn_sad_u8(v1, v2, 0u);
-    }
-}
-
 // Evaluate block (r, c): returns the winning candidate MV.  All LPB lanes of the group call it
 // with the same (r, c); `sub` is the lane's row inside the block.  use_new = bit mask of the
 // candidates read from `est` instead of `old_grid`.
+//
+// Latency matters here (the solver walks dependency chains through this function), so the memory
+// work is two trips: (1) all nine candidate MVs, (2) every image row of every candidate.  Loads are
+// unconditional -- absent neighbours and out-of-image candidates read a clamped, harmless address
+// and are masked afterwards -- because a load inside a divergent `if` costs its own round trip.
 template <int BS, bool COHERENT>
 __device__ __forceinline__ mv_t eval_block(const RegArgs &a, int r, int c, int sub, uint32_t use_new)
 {
 #pragma clang fp contract(off)
     constexpr int LPB = RegCfg<BS>::LPB;
+    constexpr int NW = BS >= 4 ? BS / 4 : 1;              // dwords per image row segment
+    constexpr int RPL = BS >= 4 ? BS / LPB : 2;           // rows per lane
+    // ---- trip 1: candidates --------------------------------------------------------------
     mv_t cand[9];
     uint32_t present = 0;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         const int rr = r + kNbRow[k], cc = c + kNbCol[k];
-        cand[k] = 0;
-        if (rr >= 0 && rr < a.rows && cc >= 0 && cc < a.cols) {
-            present |= 1u << k;
-            if ((use_new >> k) & 1u)
-                cand[k] = load_est<COHERENT>(a.est + (size_t)rr * a.cols + cc);
-            else
-                cand[k] = a.old_grid[(size_t)(rr >> a.old_shift) * a.old_cols + (cc >> a.old_shift)];
-        }
+        if (rr >= 0 && rr < a.rows && cc >= 0 && cc < a.cols) present |= 1u << k;
+        const int rs = min(max(rr, 0), a.rows - 1), cs = min(max(cc, 0), a.cols - 1);
+        if ((use_new >> k) & 1u)
+            cand[k] = load_est<COHERENT>(a.est + (size_t)rs * a.cols + cs);
+        else
+            cand[k] = a.old_grid[(size_t)(rs >> a.old_shift) * a.old_cols + (cs >> a.old_shift)];
     }
     const int bx = c * BS, by = r * BS;
-    float energy[9];
+    // ---- trip 2: image rows ----------------------------------------------------------------
     uint32_t inside = 0;
+    uint32_t cur[RPL][NW];
+    uint32_t win[9][RPL][NW + 1];
+    int shb[9];
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+        const int y1 = by + sub + i * LPB;
+        if constexpr (BS >= 4) {
+            const uint32_t *p1 = reinterpret_cast<const uint32_t *>(a.image1 + (size_t)y1 * a.width + bx);
+#pragma unroll
+            for (int q = 0; q < NW; ++q) cur[i][q] = p1[q];
+        } else {
+            const uint8_t *p1 = a.image1 + (size_t)y1 * a.width + bx;
+            cur[i][0] = (uint32_t)p1[0] | ((uint32_t)p1[1] << 8);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        int x2 = bx + mv_x(cand[k]), y2 = by + mv_y(cand[k]);
+        const bool ok = ((present >> k) & 1u) &&
+                        !(x2 < 0 || x2 > a.width - BS || y2 < 0 || y2 > a.height - BS);   // :578
+        if (ok) inside |= 1u << k;
+        else { x2 = bx; y2 = by; }                          // harmless address; result is discarded
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            const int yy = y2 + sub + i * LPB;
+            if constexpr (BS >= 4) {
+                const int ax = x2 & ~3;
+                shb[k] = x2 & 3;
+                // the dword past the row is only used when shb != 0, and then it holds row bytes
+                // (planes are allocated with slack, so the very last row may be over-read by 3 bytes)
+                const uint32_t *p2 = reinterpret_cast<const uint32_t *>(a.image2 + (size_t)yy * a.width + ax);
+#pragma unroll
+                for (int q = 0; q <= NW; ++q) win[k][i][q] = p2[q];
+            } else {
+                shb[k] = 0;
+                const uint8_t *p2 = a.image2 + (size_t)yy * a.width + x2;
+                win[k][i][0] = (uint32_t)p2[0] | ((uint32_t)p2[1] << 8);
+                win[k][i][1] = 0;
+            }
+        }
+    }
+    // ---- SADs, reduced over the block's lanes ---------------------------------------------------
+    float energy[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         uint32_t sad = 0;
-        if ((present >> k) & 1u) {
-            const int x2 = bx + mv_x(cand[k]), y2 = by + mv_y(cand[k]);
-            if (!(x2 < 0 || x2 > a.width - BS || y2 < 0 || y2 > a.height - BS)) {   // :578
-                inside |= 1u << k;
-                if constexpr (BS >= 4) {
 #pragma unroll
-                    for (int rw = sub; rw < BS; rw += LPB)
-                        sad += row_sad<BS>(a, bx, by + rw, x2, y2 + rw);
-                } else {
-                    sad = row_sad<BS>(a, bx, by, x2, y2) + row_sad<BS>(a, bx, by + 1, x2, y2 + 1);
-                }
+        for (int i = 0; i < RPL; ++i) {
+            if constexpr (BS >= 4) {
+#pragma unroll
+                for (int q = 0; q < NW; ++q)
+                    sad = __builtin_amdgcn_sad_u8(cur[i][q],
+                              __builtin_amdgcn_alignbyte(win[k][i][q + 1], win[k][i][q], shb[k]), sad);
+            } else {
+                sad = __builtin_amdgcn_sad_u8(cur[i][0], win[k][i][0], sad);
             }
         }
         if constexpr (LPB > 1) {
@@ -464,19 +482,28 @@ __device__ __forceinline__ mv_t eval_block(const RegArgs &a, int r, int c, int s
 }
 
 // ---- work-list state ---------------------------------------------------------------------
-// Two bits per block in `qbits` (16 blocks per word):
-//   QUEUED  the block sits in exactly one queue (a wave's LDS queue or a global list);
-//   BUSY    one wave is evaluating it right now.
-// Rules (every access is an agent-scope atomic, so they hold across XCDs):
-//   pop    QUEUED -> 0 (and BUSY -> 1 in k_reg_solve), COMPLETED before any input is loaded, so a
-//          change that lands after the loads finds QUEUED clear and queues the block again;
-//   push   after the changed estimate has been stored AND that store has completed: set QUEUED;
-//          the pusher enqueues the block only if neither bit was set before -- if BUSY was set,
-//          the evaluating wave re-queues it itself when it clears BUSY and finds QUEUED set.
-// Hence no block is ever evaluated by two waves at once, and every block whose inputs changed
-// after its last evaluation is queued: when all queues are empty the field is the fixed point.
-__device__ __forceinline__ uint32_t q_bit(uint32_t x) { return 1u << (2 * (x & 15)); }
-__device__ __forceinline__ uint32_t b_bit(uint32_t x) { return 2u << (2 * (x & 15)); }
+// One 16-bit counter per block in `own` (two blocks per word), agent-scope atomics only:
+//   0      nobody is responsible for the block;
+//   >= 1   exactly one wave OWNS it: it sits in that wave's LDS queue (or on a global list) or is
+//          being evaluated by it.  Only the owner ever evaluates the block and stores its estimate;
+//   >= 2   an input changed after the owner took it: the owner must evaluate it once more.
+// claim  fetch_add(1) -- issued by a wave that changed one of the block's inputs, AFTER that
+//        store has completed (and by the scan for blocks pass 1 left stale).  Old value 0: the
+//        caller becomes the owner and queues the block; its input loads come after this atomic,
+//        so they see every change made before it.  Old value > 0: the owner will redo it.
+// release after the owner's own store has completed: fetch_and(0).  Old value >= 2: claim again.
+// Every change is followed by a claim on each dependant, every claimed block is evaluated with
+// inputs loaded after the claim, and no two waves evaluate one block at the same time; when every
+// queue is empty the field is the fixed point.
+__device__ __forceinline__ uint32_t own_shift(uint32_t x) { return 16u * (x & 1u); }
+__device__ __forceinline__ uint32_t own_claim(uint32_t *own, uint32_t x)      // returns the old counter
+{
+    return (atomicAdd(&own[x >> 1], 1u << own_shift(x)) >> own_shift(x)) & 0xffffu;
+}
+__device__ __forceinline__ uint32_t own_release(uint32_t *own, uint32_t x)    // returns the old counter
+{
+    return (atomicAnd(&own[x >> 1], ~(0xffffu << own_shift(x))) >> own_shift(x)) & 0xffffu;
+}
 #define BBME_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
 template <int BS>
@@ -484,7 +511,7 @@ __global__ __launch_bounds__(256) void k_reg_pass1(RegArgs a)
 {
     constexpr int LPB = RegCfg<BS>::LPB;
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t == 0) { a.counters[0] = 0; a.counters[1] = 0; a.counters[2] = 0; a.counters[3] = 0; a.counters[4] = 0; }
+    if (t == 0) { a.counters[0] = 0; a.counters[1] = 0; a.counters[2] = 0; a.counters[3] = 0; a.counters[4] = 0; a.counters[6] = 0; a.counters[7] = 0; a.counters[8] = 0; }
     const long long g = t / LPB;
     const int sub = (int)(t % LPB);
     if (g >= (long long)a.rows * a.cols) return;   // whole groups drop out together (LPB | 256)
@@ -493,35 +520,83 @@ __global__ __launch_bounds__(256) void k_reg_pass1(RegArgs a)
     if (sub == 0) a.est[g] = res;
 }
 
-// pass 2, pull form, detection only: a block must be re-evaluated iff one of its already-updated
-// inputs (L, UL, U, UR) came out of pass 1 different from the old value pass 1 assumed for it.
-// Such blocks are queued on list1 (length counters[0]).  One thread per block.
-__global__ __launch_bounds__(256) void k_reg_detect(RegArgs a)
+// Is block (r, c) stale after pass 1?  Pull form: it must be re-evaluated iff one of its
+// already-updated inputs (L, UL, U, UR) came out of pass 1 different from the old value that
+// pass 1 assumed for it.
+__device__ __forceinline__ bool block_is_stale(const RegArgs &a, int r, int c)
 {
-    const long long x = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (x >= (long long)a.rows * a.cols) return;
-    const int r = (int)(x / a.cols), c = (int)(x % a.cols);
     bool stale = false;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         if (!((BBME_NEW_MASK >> k) & 1u)) continue;
         const int rr = r + kNbRow[k], cc = c + kNbCol[k];
         if (rr < 0 || rr >= a.rows || cc < 0 || cc >= a.cols) continue;
-        const mv_t e = a.est[(size_t)rr * a.cols + cc];
+        const mv_t e = a.est[(size_t)rr * a.cols + cc];                       // as pass 1 wrote it
         const mv_t o = a.old_grid[(size_t)(rr >> a.old_shift) * a.old_cols + (cc >> a.old_shift)];
         stale |= (e != o);
     }
-    if (stale) {
-        atomicOr(&a.qbits[x >> 4], q_bit((uint32_t)x));
-        a.list1[atomicAdd(&a.counters[0], 1u)] = (uint32_t)x;
+    return stale;
+}
+
+// One work-list pass of the safety net (see k_reg_solve's epilogue): `nthreads` threads of one
+// workgroup, lists in global memory that cannot overflow (a block is on a list at most once).
+template <int BS>
+__device__ __forceinline__ void drain_lists(const RegArgs &a, int t, int nthreads)
+{
+    constexpr int LPB = RegCfg<BS>::LPB;
+    const int group = t / LPB, ngroups = nthreads / LPB, sub = t % LPB;
+    // pass p reads list[p&1] (length counters[p%3]), appends to list[(p+1)&1] (counters[(p+1)%3])
+    // and zeroes counters[(p+2)%3]; the overflow list of the solver is list0 / counters[1] -> p = 4.
+    int p = 4;
+    // a change can only travel along the raster dependency chain, whose length is below
+    // 2*rows + cols; the cap is an exit every wave reaches even if that reasoning were wrong
+    const int p_max = p + 2 * a.rows + a.cols + 16;
+    for (;;) {
+        const uint32_t n = __hip_atomic_load(&a.counters[p % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n == 0) break;
+        if (p > p_max) { if (t == 0) a.counters[5] = 1; break; }      // reported by bbme_last_sweep_passes
+        __syncthreads();                              // everyone has read n before it can be reused
+        if (t == 0) {
+            __hip_atomic_store(&a.counters[(p + 2) % 3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.counters[3] += 1;
+        }
+        const uint32_t *lcur = (p & 1) ? a.list1 : a.list0;
+        uint32_t *lnext = (p & 1) ? a.list0 : a.list1;
+        uint32_t *cnext = &a.counters[(p + 1) % 3];
+        for (uint32_t idx = group; idx < n; idx += ngroups) {
+            const uint32_t x = __hip_atomic_load(&lcur[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int r = (int)(x / a.cols), c = (int)(x % a.cols);
+            if (sub == 0) own_release(a.own, x);                                  // the list owned it
+            BBME_DRAIN();
+            const mv_t res = eval_block<BS, true>(a, r, c, sub, BBME_NEW_MASK);
+            if (sub == 0 && res != load_est<true>(a.est + x)) {
+                __hip_atomic_store(a.est + x, res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                BBME_DRAIN();
+                const int dr[4] = {0, 1, 1, 1}, dc[4] = {1, 1, 0, -1};
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int rr = r + dr[d], cc = c + dc[d];
+                    if (rr >= a.rows || cc < 0 || cc >= a.cols) continue;
+                    const uint32_t xd = (uint32_t)rr * a.cols + cc;
+                    if (own_claim(a.own, xd) == 0)
+                        __hip_atomic_store(&lnext[atomicAdd(cnext, 1u)], xd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        BBME_DRAIN();
+        __syncthreads();
+        ++p;
     }
 }
 
-// Asynchronous solver.  Every wave owns a private LDS queue.  It takes chunks of the global list,
-// and whatever its own changes make stale it queues locally and evaluates itself, round after
-// round, without any grid-wide step: fixed-point iteration tolerates any evaluation order.  A wave
-// whose queue is empty and which has no chunk left simply exits.  If a local queue is full the
-// surplus goes to the overflow list, which k_reg_tail (below) finishes.
+// Asynchronous solver.  Every wave owns a private LDS queue.  It scans its share of the grid for
+// blocks that pass 1 left stale (64 blocks at a time), queues them, and whatever its own changes
+// make stale it queues locally too and evaluates itself, round after round, without any grid-wide
+// step: fixed-point iteration tolerates any evaluation order.  A wave whose queue is empty and
+// which has scanned its share simply exits.  If a local queue is full the surplus goes to a
+// global overflow list; the workgroup that finishes last (ticket counter) drains that list on its
+// own, so the launch always ends at the fixed point.
 template <int BS>
 __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
 {
@@ -529,12 +604,12 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
     constexpr int NB = 64 / LPB;                 // blocks evaluated per wave per round
     constexpr uint32_t QCAP = 1024;
     __shared__ uint32_t qmem[4][QCAP];
+    __shared__ uint32_t s_ticket;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint32_t *q = qmem[wave];
     const uint32_t w = blockIdx.x * 4 + wave, W = gridDim.x * 4;
-    const uint32_t n = a.counters[0];
-    const uint32_t *in_list = a.list1;
+    const uint32_t nblocks = (uint32_t)a.rows * a.cols;
     uint32_t *ovf_list = a.list0;
     uint32_t *ovf_count = &a.counters[1];
     const int g = lane / LPB, sub = lane % LPB;
@@ -553,17 +628,21 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
         if (tail - head + total <= QCAP) {
             if (flag) q[(tail + (uint32_t)__popcll(m & lt_mask)) % QCAP] = v;
             tail = __builtin_amdgcn_readfirstlane(tail + total);
-        } else if (flag) {
-            ovf_list[atomicAdd(ovf_count, 1u)] = v;        // stays QUEUED; k_reg_tail takes it
+        } else if (flag) {                                  // stays QUEUED; drained in the epilogue
+            __hip_atomic_store(&ovf_list[atomicAdd(ovf_count, 1u)], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
 
-    for (uint32_t chunk = w;; chunk += W) {
-        const uint32_t base = chunk * NB;
-        if (base < n) {
-            const uint32_t take = min((uint32_t)NB, n - base);
-            if ((uint32_t)lane < take) q[(tail + lane) % QCAP] = in_list[base + lane];
-            tail = __builtin_amdgcn_readfirstlane(tail + take);
+    // scan granularity: two rounds' worth of blocks, so that a cluster of stale blocks is spread
+    // over many waves instead of queueing up behind one
+    constexpr uint32_t SCAN = (2 * NB < 64) ? 2 * NB : 64;
+    for (uint32_t base = w * SCAN;; base += W * SCAN) {
+        if (base < nblocks) {
+            const uint32_t x = base + lane;
+            bool mine = false;
+            if ((uint32_t)lane < SCAN && x < nblocks && block_is_stale(a, (int)(x / a.cols), (int)(x % a.cols)))
+                mine = own_claim(a.own, x) == 0;
+            enqueue(mine, x);
         } else if (head == tail) {
             break;
         }
@@ -571,11 +650,9 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
             if (++rounds > round_cap) { if (lane == 0) a.counters[5] = 1; head = tail; break; }
             const uint32_t cnt = min((uint32_t)NB, tail - head);
             const bool active = (uint32_t)g < cnt;
-            const uint32_t x = active ? q[(head + g) % QCAP] : 0u;
+            const uint32_t x = active ? q[(head + g) % QCAP] : 0u;      // owned since it was claimed
             head = __builtin_amdgcn_readfirstlane(head + cnt);
             const bool leader = active && sub == 0;
-            if (leader) atomicXor(&a.qbits[x >> 4], q_bit(x) | b_bit(x));      // pop: QUEUED -> 0, BUSY -> 1
-            BBME_DRAIN();
             bool changed = false;
             int r = 0, c = 0;
             if (active) {
@@ -588,81 +665,39 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
             }
             evaluated += cnt;
             if (__ballot(changed)) BBME_DRAIN();                       // the stores have completed
-            // one trip for all five atomics: queue the dependants R, DR, D, DL and clear BUSY
+            // one trip for all five atomics: claim the dependants R, DR, D, DL and release x
             const int dr[4] = {0, 1, 1, 1}, dc[4] = {1, 1, 0, -1};
-            uint32_t xd[4], oldw[4];
+            uint32_t xd[4], was[4];
             bool want[4];
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 const int rr = r + dr[d], cc = c + dc[d];
                 want[d] = changed && rr < a.rows && cc >= 0 && cc < a.cols;
                 xd[d] = want[d] ? (uint32_t)rr * a.cols + cc : 0u;
-                oldw[d] = 0;
-                if (want[d]) oldw[d] = atomicOr(&a.qbits[xd[d] >> 4], q_bit(xd[d]));
+                was[d] = 1;
+                if (want[d]) was[d] = own_claim(a.own, xd[d]);
             }
-            uint32_t oldx = 0;
-            if (leader) oldx = atomicAnd(&a.qbits[x >> 4], ~b_bit(x));           // BUSY -> 0
+            uint32_t wasx = 0;
+            if (leader) wasx = own_release(a.own, x);
 #pragma unroll
-            for (int d = 0; d < 4; ++d)
-                enqueue(want[d] && !(oldw[d] & (q_bit(xd[d]) | b_bit(xd[d]))), xd[d]);
-            enqueue(leader && (oldx & q_bit(x)) != 0, x);              // queued while we were evaluating it
+            for (int d = 0; d < 4; ++d) enqueue(want[d] && was[d] == 0, xd[d]);
+            // an input changed while we held x: take it again (unless somebody else just did)
+            bool again = false;
+            if (leader && wasx >= 2) again = own_claim(a.own, x) == 0;
+            enqueue(again, x);
+            if (wasx >= 0x8000u) a.counters[5] = 1;                    // counter close to overflow: report
         }
     }
-    if (lane == 0 && evaluated) atomicAdd(&a.counters[4], evaluated);
-}
+    if (lane == 0 && evaluated) { atomicAdd(&a.counters[4], evaluated); atomicMax(&a.counters[7], rounds); atomicAdd(&a.counters[8], rounds); }
 
-// Safety net: single workgroup, global lists that cannot overflow (a block is on a list at most once),
-// loops pass by pass until a pass queues nothing.  Pass p reads list[p&1] (length counters[p%3]),
-// appends to list[(p+1)&1] (counters[(p+1)%3]) and zeroes counters[(p+2)%3].  It normally finds the
-// overflow list of k_reg_solve empty and exits at once.
-template <int BS>
-__global__ __launch_bounds__(1024) void k_reg_tail(RegArgs a)
-{
-    constexpr int LPB = RegCfg<BS>::LPB;
-    const int t = threadIdx.x;
-    const int group = t / LPB, ngroups = 1024 / LPB, sub = t % LPB;
-    int p = a.pass;
-    // a change can only travel along the raster dependency chain, whose length is below
-    // 2*rows + cols; the cap is an exit every wave reaches even if that reasoning were wrong
-    const int p_max = a.pass + 2 * a.rows + a.cols + 16;
-    for (;;) {
-        const uint32_t n = __hip_atomic_load(&a.counters[p % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (n == 0) break;
-        if (p > p_max) { if (t == 0) a.counters[5] = 1; break; }      // reported by bbme_last_sweep_passes
-        __syncthreads();                              // everyone has read n before it can be reused
-        if (t == 0) {
-            __hip_atomic_store(&a.counters[(p + 2) % 3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a.counters[3] += 1;
-            a.counters[4] += n;
-        }
-        const uint32_t *lcur = (p & 1) ? a.list1 : a.list0;
-        uint32_t *lnext = (p & 1) ? a.list0 : a.list1;
-        uint32_t *cnext = &a.counters[(p + 1) % 3];
-        for (uint32_t idx = group; idx < n; idx += ngroups) {
-            const uint32_t x = __hip_atomic_load(&lcur[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int r = (int)(x / a.cols), c = (int)(x % a.cols);
-            if (sub == 0) atomicAnd(&a.qbits[x >> 4], ~q_bit(x));                 // pop
-            BBME_DRAIN();
-            const mv_t res = eval_block<BS, true>(a, r, c, sub, BBME_NEW_MASK);
-            if (sub == 0 && res != load_est<true>(a.est + x)) {
-                __hip_atomic_store(a.est + x, res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                BBME_DRAIN();
-                const int dr[4] = {0, 1, 1, 1}, dc[4] = {1, 1, 0, -1};
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const int rr = r + dr[d], cc = c + dc[d];
-                    if (rr >= a.rows || cc < 0 || cc >= a.cols) continue;
-                    const uint32_t xd = (uint32_t)rr * a.cols + cc;
-                    if (!(atomicOr(&a.qbits[xd >> 4], q_bit(xd)) & q_bit(xd)))
-                        lnext[atomicAdd(cnext, 1u)] = xd;
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        BBME_DRAIN();
-        __syncthreads();
-        ++p;
-    }
+    // epilogue: the workgroup that takes the last ticket knows every other one has finished (their
+    // stores were drained before they took theirs) and empties the overflow list, if there is one
+    BBME_DRAIN();
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&a.counters[6], 1u);
+    __syncthreads();
+    if (s_ticket != gridDim.x - 1) return;
+    drain_lists<BS>(a, threadIdx.x, 256);
 }
 
 // =======================================================================================

@@ -158,6 +158,11 @@ class MF:
         _capi.check(self._lib.bbme_last_sweep_passes(self._ctx, v))
         return v[0], v[1]
 
+    def sweep_stats(self):
+        v = (C.c_uint * 16)()
+        _capi.check(self._lib.bbme_sweep_stats(self._ctx, v))
+        return list(v)
+
     def set_profiling(self, enabled):
         _capi.check(self._lib.bbme_set_profiling(self._ctx, int(enabled)))
 

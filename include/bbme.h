@@ -139,6 +139,10 @@ int bbme_stage_get_mvs(bbme_ctx *ctx, int level, int block, int16_t *mvs);
 int bbme_stage_set_mvs(bbme_ctx *ctx, int level, int block, const int16_t *mvs);
 /* copy_to_all_pixels (:815-826) on level 0 after its last divide: fills the dense field. */
 int bbme_stage_expand(bbme_ctx *ctx);
+/* Raw counters of the last sweep (diagnostic, 16 words): [3] safety-net passes, [4] blocks
+ * re-evaluated by the solver, [5] non-convergence flag, [7] most rounds run by one wave,
+ * [8] rounds summed over waves. */
+int bbme_sweep_stats(bbme_ctx *ctx, unsigned *stats16);
 /* Fix-up passes the last sweep needed after its first full pass (diagnostic). */
 int bbme_last_sweep_passes(bbme_ctx *ctx, int *passes);
 
