@@ -40,6 +40,24 @@ def level_blocks(pw, ph, block, levels):
     return [((pw >> l) // block) * ((ph >> l) // block) for l in range(levels)]
 
 
+def pmc_traffic(levels):
+    """Mean HBM-side bytes per search launch from the committed rocprofv3 --pmc passes
+    (profiles/r01_pmc_search.json, made by scripts/pmc_report.py: FETCH_SIZE scaled by the factor
+    measured on a calibration read of known size in the same run, plus WRITE_SIZE).  Only quoted
+    when that file was measured on exactly this kernel source; otherwise None."""
+    import hashlib
+    path = os.path.join(ROOT, "profiles", "r01_pmc_search.json")
+    src = os.path.join(ROOT, "blockbasedmotionestimation_amd", "csrc", "bbme_kernels.hpp")
+    try:
+        d = json.load(open(path))
+        if d.get("kernel_source_sha256") != hashlib.sha256(open(src, "rb").read()).hexdigest():
+            return None
+        vals = [v["hbm_bytes"] for k, v in d["kernels"].items() if k.startswith("k_search")]
+        return sum(vals) / len(vals) if len(vals) == levels else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(f1, f2, search, block, levels, expect_flow):
     """The oracle (CPU restatement, 1 thread, rebuilt here with -march=native) timed on the same pair."""
     src = os.path.join(ROOT, "oracle", "bbme_oracle.c")
@@ -164,9 +182,10 @@ def main():
                        "block": block, "search_range": R, "levels": levels,
                        "blocks_level0": blocks[0], "blocks_all_levels": sum(blocks),
                        "multi_gpu": "one pair per GPU, dense flow gathered to rank 0 (RCCL)" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "k_search_generic<%d> (mean of the %d per-level launches)" % (block, levels),
+            "roofline": {"bound": "hbm", "kernel": "k_search_fast<%d> (mean of the %d per-level launches)" % (block, levels),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(levels),
+                         "algorithmic_bytes_per_launch": round(search_bytes),
                          "avg_launch_ms": round(search_ms, 5),
                          "note": "kernel is integer-SAD VALU bound, not HBM bound (SURVEY 8d)",
                          "valu_sad": {"achieved_Tabsdiff_s": round(absdiff / (search_ms * 1e-3) / 1e12, 3),

@@ -13,8 +13,10 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libbbme.so")
+CLI = os.path.join(PKG, "bbme_cli")
 SOURCES = ["bbme_host.cpp", "bbme_device.hip"]
-HEADERS = ["bbme_internal.hpp", "bbme_kernels.hpp", os.path.join(ROOT, "include", "bbme.h")]
+HEADERS = ["bbme_internal.hpp", "bbme_kernels.hpp", "motion_framework.hpp", "rw_flow.hpp", "bbme_main.cpp",
+           os.path.join(ROOT, "include", "bbme.h")]
 ARCH = "gfx950"
 
 
@@ -26,7 +28,7 @@ def _hipcc():
 
 
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(CLI):
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + \
@@ -47,6 +49,14 @@ def build(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
+    # the C++ host side (MF / Flow classes + the reference's driver as a CLI) links only the C-ABI
+    cli = ["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+           os.path.join(CSRC, "bbme_main.cpp"), "-o", CLI + ".tmp", "-L", PKG, "-lbbme",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + "/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cli))
+    subprocess.check_call(cli)
+    os.replace(CLI + ".tmp", CLI)
     return LIB
 
 

@@ -692,6 +692,27 @@ int bbme_get_timings(bbme_ctx *c, float *total, float *search, float *reg, float
     return BBME_OK;
 }
 
+int bbme_calibrate_read(int device, unsigned mbytes, int repeats)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return bbme::fail(BBME_ERR_HIP, "no HIP device %d", device);
+    if (mbytes == 0 || mbytes > 16384 || repeats < 1) return bbme::fail(BBME_ERR_INVALID, "bbme_calibrate_read: bad size");
+    HIP_TRY(hipSetDevice(device));
+    const size_t bytes = (size_t)mbytes << 20, n = bytes / 4;
+    uint32_t *buf = nullptr, *out = nullptr;
+    HIP_TRY(hipMalloc(&buf, bytes));
+    HIP_TRY(hipMalloc(&out, 64));
+    HIP_TRY(hipMemset(buf, 1, bytes));
+    HIP_TRY(hipDeviceSynchronize());
+    for (int i = 0; i < repeats; ++i)
+        hipLaunchKernelGGL(k_calib_read_dword, dim3(256 * 8), dim3(256), 0, 0, buf, n, out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    (void)hipFree(buf); (void)hipFree(out);
+    return BBME_OK;
+}
+
 int bbme_selftest_isa(int device, int *mismatches)
 {
     if (!mismatches) return bbme::fail(BBME_ERR_INVALID, "null output");

@@ -770,6 +770,19 @@ __global__ __launch_bounds__(256) void k_pyr_down(const uint8_t *src, int sw, in
 }
 
 // =======================================================================================
+// PMC calibration (bbme_calibrate_read): reads n dwords once with one aligned dword per lane --
+// the access shape of the search kernel's window staging -- so that FETCH_SIZE can be scaled by a
+// known byte count before it is quoted (MI355X_MICROARCH.md, HBM section).
+// =======================================================================================
+__global__ __launch_bounds__(256) void k_calib_read_dword(const uint32_t *p, size_t n, uint32_t *out)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) acc += p[i];
+    if (acc == 0x12345678u) out[0] = acc;            // keeps the loads alive, practically never taken
+}
+
+// =======================================================================================
 // instruction probes (bbme_selftest_isa)
 // =======================================================================================
 __global__ void k_probe_sad(const uint32_t *a, const uint32_t *b, const uint32_t *c,

@@ -152,6 +152,11 @@ int bbme_set_profiling(bbme_ctx *ctx, int enabled);
 int bbme_get_timings(bbme_ctx *ctx, float *total_ms, float *search_ms, float *regularize_ms,
                      float *expand_ms, float *search_level0_ms);
 
+/* Profiling aid: launches a kernel that reads `mbytes` MiB exactly once with one aligned dword per
+ * lane (the access shape of the search kernel's window staging), `repeats` times, so that the
+ * FETCH_SIZE counter can be calibrated against a known byte count in the same rocprofv3 run. */
+int bbme_calibrate_read(int device, unsigned mbytes, int repeats);
+
 /* Instruction probes used by the GPU test-suite: checks v_sad_u8, v_alignbyte_b32,
  * v_qsad_pk_u16_u8 and v_sad_u16 against a scalar model on 65536 random operands.
  * mismatches[0..3] receive the number of disagreements per instruction, in that order. */

@@ -1,0 +1,76 @@
+"""world_size-2 gloo test of the multi-GPU path's host logic: pairs sharded p % world, whole
+pyramid per pair with no exchange, one gather of the dense fields on rank 0, .flo files written
+there.  No GPU here, so the per-pair compute is injected (the CPU oracle stands in for the HIP
+kernels as the checker's view of what a rank must produce); everything else is the product code."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir, n_pairs):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from blockbasedmotionestimation_amd.sequence import estimate_sequence, shard_pairs
+    from blockbasedmotionestimation_amd.synth import synth_pair
+    from oracle import bbme_oracle as O
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    search, block = [30, 30], [16, 16]
+
+    def compute(f1, f2):
+        omf = O.OracleMF(f1, f2, search, block)
+        flow = omf.calc_motion_block_matching()
+        py, px = omf.padding_y, omf.padding_x
+        return np.ascontiguousarray(flow[py:py + f1.shape[0], px:px + f1.shape[1]])
+
+    pairs = {p: synth_pair(160, 96, 500 + p, max_motion=6)[:2] for p in shard_pairs(n_pairs, rank, world)}
+    res = estimate_sequence(pairs, search, block, n_pairs=n_pairs, out_dir=out_dir if rank == 0 else None,
+                            compute=compute)
+    assert (res is not None) == (rank == 0)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "gathered.npy"), np.stack(res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_pairs", [2, 5])
+def test_two_rank_sequence_gather(tmp_path, oracle, bbme, n_pairs):
+    import torch.multiprocessing as mp
+    from blockbasedmotionestimation_amd.sequence import shard_pairs
+    assert shard_pairs(5, 0, 2) == [0, 2, 4] and shard_pairs(5, 1, 2) == [1, 3]
+    out_dir = str(tmp_path)
+    mp.spawn(_worker, args=(2, _free_port(), out_dir, n_pairs), nprocs=2, join=True)
+    got = np.load(os.path.join(out_dir, "gathered.npy"))
+    assert got.shape == (n_pairs, 96, 160, 2)
+    for p in range(n_pairs):
+        f1, f2, _ = bbme.synth_pair(160, 96, 500 + p, max_motion=6)
+        omf = oracle.OracleMF(f1, f2, [30, 30], [16, 16])
+        exp = omf.calc_motion_block_matching()[omf.padding_y:omf.padding_y + 96, omf.padding_x:omf.padding_x + 160]
+        assert np.array_equal(got[p], exp), "pair %d" % p
+        assert np.array_equal(bbme.Flow().ReadFlowFile(os.path.join(out_dir, "%04d.flo" % p)), exp)
+
+
+def test_single_process_sequence(bbme, oracle):
+    from blockbasedmotionestimation_amd.sequence import estimate_sequence
+    pairs = {p: bbme.synth_pair(96, 64, 900 + p, max_motion=4)[:2] for p in range(3)}
+    calls = []
+
+    def compute(f1, f2):
+        calls.append(1)
+        return np.zeros(f1.shape + (2,), np.float32)
+    res = estimate_sequence(pairs, [30], [16], compute=compute)
+    assert len(res) == 3 and len(calls) == 3

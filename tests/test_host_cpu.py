@@ -147,3 +147,22 @@ def test_synth_pair_is_deterministic(bbme):
     dx, dy = (int(v) for v in mo[0, 0])
     ys, xs = np.mgrid[8:56, 8:88]
     assert np.array_equal(f2[ys + dy, xs + dx], f1[ys, xs])
+
+
+def test_cli_builds_and_fails_loudly_without_gpu(bbme, tmp_path):
+    """The C++ host side (MF / Flow classes + the reference driver as a CLI) links only the C-ABI."""
+    import subprocess
+    from blockbasedmotionestimation_amd import build as _build
+    assert os.path.exists(_build.CLI)
+    r = subprocess.run([_build.CLI], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+    img = np.zeros((40, 48), np.uint8)
+    for name in ("a.pgm", "b.pgm"):
+        with open(tmp_path / name, "wb") as f:
+            f.write(b"P5\n48 40\n255\n" + img.tobytes())
+    r = subprocess.run([_build.CLI, str(tmp_path / "a.pgm"), str(tmp_path / "missing.pgm")], capture_output=True, text=True)
+    assert r.returncode == 1 and "Could not open one of the images" in r.stderr
+    if not os.path.exists("/dev/kfd"):
+        r = subprocess.run([_build.CLI, str(tmp_path / "a.pgm"), str(tmp_path / "b.pgm"), "--levels", "1", "--block", "16",
+                            "--search", "30"], capture_output=True, text=True)
+        assert r.returncode == 1 and "no CPU fallback" in r.stderr
