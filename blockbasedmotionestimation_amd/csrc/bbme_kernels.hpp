@@ -338,6 +338,11 @@ struct RegArgs {
     // work lists
     uint32_t *list0, *list1;    // block indices
     uint32_t *own;              // ownership counters, 16 bits per block (see "work-list state" below)
+    // tiling of the grid (k_reg_tile) and the epoch flags with which tiles notify their neighbours
+    int tile_h, tile_w, tiles_x;
+    uint32_t *tile_flags;       // [tile] = epoch of the launch that must look at the tile again
+    uint32_t epoch;             // epoch of this launch
+    int first;                  // k_reg_tile: 1 = first launch of the sweep (pass 1 for every tile)
     uint32_t *counters;         // [0..2] list lengths (rotating), [3] safety-net passes, [4] blocks re-evaluated,
                                 // [5] sticky: a sweep hit a cap without converging, [6] solver ticket
 };
@@ -362,52 +367,31 @@ __device__ __forceinline__ mv_t load_est(const mv_t *p)
         return *p;
 }
 
-// Evaluate block (r, c): returns the winning candidate MV.  All LPB lanes of the group call it
-// with the same (r, c); `sub` is the lane's row inside the block.  use_new = bit mask of the
-// candidates read from `est` instead of `old_grid`.
-//
-// Latency matters here (the solver walks dependency chains through this function), so the memory
-// work is two trips: (1) all nine candidate MVs, (2) every image row of every candidate.  Loads are
-// unconditional -- absent neighbours and out-of-image candidates read a clamped, harmless address
-// and are masked afterwards -- because a load inside a divergent `if` costs its own round trip.
-template <int BS, bool COHERENT>
-__device__ __forceinline__ mv_t eval_block(const RegArgs &a, int r, int c, int sub, uint32_t use_new)
+// Score the (up to nine) candidates of block (bx, by) and return the winner: find_min_candidate,
+// calculate_smoothness, min_energy_candidate (motion_framework.cpp:532-662).  All LPB lanes of the
+// block's group call it; `sub` is the lane's row inside the block; `present` marks the neighbours
+// that exist in the grid.  Every image row of every candidate is loaded in ONE memory trip: loads are
+// unconditional -- out-of-image candidates read a clamped, harmless address and are masked afterwards
+// -- because a load inside a divergent `if` costs its own round trip.
+template <int BS>
+__device__ __forceinline__ mv_t score_block(const RegArgs &a, const mv_t (&cand)[9], uint32_t present,
+                                            int bx, int by, int sub)
 {
 #pragma clang fp contract(off)
     constexpr int LPB = RegCfg<BS>::LPB;
     constexpr int NW = BS >= 4 ? BS / 4 : 1;              // dwords per image row segment
     constexpr int RPL = BS >= 4 ? BS / LPB : 2;           // rows per lane
-    // ---- trip 1: candidates --------------------------------------------------------------
-    mv_t cand[9];
-    uint32_t present = 0;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const int rr = r + kNbRow[k], cc = c + kNbCol[k];
-        if (rr >= 0 && rr < a.rows && cc >= 0 && cc < a.cols) present |= 1u << k;
-        const int rs = min(max(rr, 0), a.rows - 1), cs = min(max(cc, 0), a.cols - 1);
-        if ((use_new >> k) & 1u)
-            cand[k] = load_est<COHERENT>(a.est + (size_t)rs * a.cols + cs);
-        else
-            cand[k] = a.old_grid[(size_t)(rs >> a.old_shift) * a.old_cols + (cs >> a.old_shift)];
-    }
-    const int bx = c * BS, by = r * BS;
-    // ---- trip 2: image rows ----------------------------------------------------------------
+    // A row segment is fetched with ONE unaligned vector load (gfx950 global loads take any byte
+    // address; bbme_selftest_isa checks it): the cost of this function is the number of load
+    // instructions a wave issues, since each one walks up to 64 different cache lines.
+    struct __attribute__((packed, aligned(1))) row_t { uint32_t v[NW]; };
+    constexpr uint32_t kMask = BS >= 4 ? 0xffffffffu : 0x0000ffffu;   // 2-pixel rows: low half of the dword
     uint32_t inside = 0;
-    uint32_t cur[RPL][NW];
-    uint32_t win[9][RPL][NW + 1];
-    int shb[9];
+    row_t cur[RPL];
+    row_t win[9][RPL];
 #pragma unroll
-    for (int i = 0; i < RPL; ++i) {
-        const int y1 = by + sub + i * LPB;
-        if constexpr (BS >= 4) {
-            const uint32_t *p1 = reinterpret_cast<const uint32_t *>(a.image1 + (size_t)y1 * a.width + bx);
-#pragma unroll
-            for (int q = 0; q < NW; ++q) cur[i][q] = p1[q];
-        } else {
-            const uint8_t *p1 = a.image1 + (size_t)y1 * a.width + bx;
-            cur[i][0] = (uint32_t)p1[0] | ((uint32_t)p1[1] << 8);
-        }
-    }
+    for (int i = 0; i < RPL; ++i)
+        cur[i] = *reinterpret_cast<const row_t *>(a.image1 + (size_t)(by + sub + i * LPB) * a.width + bx);
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         int x2 = bx + mv_x(cand[k]), y2 = by + mv_y(cand[k]);
@@ -416,23 +400,8 @@ __device__ __forceinline__ mv_t eval_block(const RegArgs &a, int r, int c, int s
         if (ok) inside |= 1u << k;
         else { x2 = bx; y2 = by; }                          // harmless address; result is discarded
 #pragma unroll
-        for (int i = 0; i < RPL; ++i) {
-            const int yy = y2 + sub + i * LPB;
-            if constexpr (BS >= 4) {
-                const int ax = x2 & ~3;
-                shb[k] = x2 & 3;
-                // the dword past the row is only used when shb != 0, and then it holds row bytes
-                // (planes are allocated with slack, so the very last row may be over-read by 3 bytes)
-                const uint32_t *p2 = reinterpret_cast<const uint32_t *>(a.image2 + (size_t)yy * a.width + ax);
-#pragma unroll
-                for (int q = 0; q <= NW; ++q) win[k][i][q] = p2[q];
-            } else {
-                shb[k] = 0;
-                const uint8_t *p2 = a.image2 + (size_t)yy * a.width + x2;
-                win[k][i][0] = (uint32_t)p2[0] | ((uint32_t)p2[1] << 8);
-                win[k][i][1] = 0;
-            }
-        }
+        for (int i = 0; i < RPL; ++i)
+            win[k][i] = *reinterpret_cast<const row_t *>(a.image2 + (size_t)(y2 + sub + i * LPB) * a.width + x2);
     }
     // ---- SADs, reduced over the block's lanes ---------------------------------------------------
     float energy[9];
@@ -440,16 +409,10 @@ __device__ __forceinline__ mv_t eval_block(const RegArgs &a, int r, int c, int s
     for (int k = 0; k < 9; ++k) {
         uint32_t sad = 0;
 #pragma unroll
-        for (int i = 0; i < RPL; ++i) {
-            if constexpr (BS >= 4) {
+        for (int i = 0; i < RPL; ++i)
 #pragma unroll
-                for (int q = 0; q < NW; ++q)
-                    sad = __builtin_amdgcn_sad_u8(cur[i][q],
-                              __builtin_amdgcn_alignbyte(win[k][i][q + 1], win[k][i][q], shb[k]), sad);
-            } else {
-                sad = __builtin_amdgcn_sad_u8(cur[i][0], win[k][i][0], sad);
-            }
-        }
+            for (int q = 0; q < NW; ++q)
+                sad = __builtin_amdgcn_sad_u8(cur[i].v[q] & kMask, win[k][i].v[q] & kMask, sad);
         if constexpr (LPB > 1) {
 #pragma unroll
             for (int o = LPB / 2; o > 0; o >>= 1) sad += __shfl_xor(sad, o);
@@ -479,6 +442,91 @@ __device__ __forceinline__ mv_t eval_block(const RegArgs &a, int r, int c, int s
 #pragma unroll
     for (int k = 1; k < 9; ++k) if (best == k) res = cand[k];
     return res;
+}
+
+// Evaluate block (r, c) with its candidates read from global memory (one trip for all nine):
+// use_new = bit mask of the candidates read from `est` instead of `old_grid`.
+template <int BS, bool COHERENT>
+__device__ __forceinline__ mv_t eval_block(const RegArgs &a, int r, int c, int sub, uint32_t use_new)
+{
+    mv_t cand[9];
+    uint32_t present = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int rr = r + kNbRow[k], cc = c + kNbCol[k];
+        if (rr >= 0 && rr < a.rows && cc >= 0 && cc < a.cols) present |= 1u << k;
+        const int rs = min(max(rr, 0), a.rows - 1), cs = min(max(cc, 0), a.cols - 1);
+        if ((use_new >> k) & 1u)
+            cand[k] = load_est<COHERENT>(a.est + (size_t)rs * a.cols + cs);
+        else
+            cand[k] = a.old_grid[(size_t)(rs >> a.old_shift) * a.old_cols + (cs >> a.old_shift)];
+    }
+    return score_block<BS>(a, cand, present, c * BS, r * BS, sub);
+}
+
+// Latency form of the evaluation, used where one wave walks a dependency chain (k_reg_solve and the
+// safety net): a lone wave issues about one instruction per four cycles, so the ~1000 instructions
+// of the nine-candidates-per-lane form above ARE the round time.  Here a block is handled by a group
+// of 16 lanes and lane k < 9 owns candidate k: its address arithmetic, its image rows, its SAD, its
+// smoothness term (the other candidates arrive by shuffle) and its energy -- the same float expression
+// as in score_block, so the same winner: lowest energy, ties to the lowest k (:648-660).
+template <int BS, bool COHERENT>
+__device__ __forceinline__ mv_t eval_block_lanes(const RegArgs &a, int r, int c, int k16, uint32_t use_new)
+{
+#pragma clang fp contract(off)
+    constexpr int NW = BS >= 4 ? BS / 4 : 1;
+    struct __attribute__((packed, aligned(1))) row_t { uint32_t v[NW]; };
+    constexpr uint32_t kMask = BS >= 4 ? 0xffffffffu : 0x0000ffffu;
+    // (drow + 1) and (dcol + 1) of candidate k, two bits each, order C,L,R,DR,UL,UR,U,D,DL (:441-449)
+    constexpr uint32_t kRowCode = 1u | 1u << 2 | 1u << 4 | 2u << 6 | 0u << 8 | 0u << 10 | 0u << 12 | 2u << 14 | 2u << 16;
+    constexpr uint32_t kColCode = 1u | 0u << 2 | 2u << 4 | 2u << 6 | 0u << 8 | 2u << 10 | 1u << 12 | 1u << 14 | 0u << 16;
+    const int k = k16 < 9 ? k16 : 0;                          // lanes 9..15 shadow candidate 0 and are ignored
+    const int rr = r + (int)((kRowCode >> (2 * k)) & 3u) - 1, cc = c + (int)((kColCode >> (2 * k)) & 3u) - 1;
+    const bool present = k16 < 9 && rr >= 0 && rr < a.rows && cc >= 0 && cc < a.cols;
+    const int rs = min(max(rr, 0), a.rows - 1), cs = min(max(cc, 0), a.cols - 1);
+    mv_t mv;
+    if ((use_new >> k) & 1u) mv = load_est<COHERENT>(a.est + (size_t)rs * a.cols + cs);
+    else mv = a.old_grid[(size_t)(rs >> a.old_shift) * a.old_cols + (cs >> a.old_shift)];
+    const int bx = c * BS, by = r * BS;
+    int x2 = bx + mv_x(mv), y2 = by + mv_y(mv);
+    const bool inside = present && !(x2 < 0 || x2 > a.width - BS || y2 < 0 || y2 > a.height - BS);   // :578
+    if (!inside) { x2 = bx; y2 = by; }
+    // SAD of this lane's candidate: the rows are independent loads, issued back to back
+    uint32_t sad = 0;
+    const uint8_t *p1 = a.image1 + (size_t)by * a.width + bx;
+    const uint8_t *p2 = a.image2 + (size_t)y2 * a.width + x2;
+#pragma unroll
+    for (int row = 0; row < BS; ++row) {
+        const row_t u = *reinterpret_cast<const row_t *>(p1 + (size_t)row * a.width);
+        const row_t w = *reinterpret_cast<const row_t *>(p2 + (size_t)row * a.width);
+#pragma unroll
+        for (int q = 0; q < NW; ++q) sad = __builtin_amdgcn_sad_u8(u.v[q] & kMask, w.v[q] & kMask, sad);
+    }
+    // smoothness: sum over the present candidates of |u_m - u_k| + |v_m - v_k| (:637-641)
+    const int lane = (int)(threadIdx.x & 63u);
+    const int base = lane & ~15;
+    const uint32_t pmask = (uint32_t)(__ballot(present) >> base) & 0x1ffu;
+    const uint32_t mine = mv ^ 0x80008000u;
+    uint32_t smooth = 0;
+#pragma unroll
+    for (int m = 0; m < 9; ++m) {
+        const uint32_t other = (uint32_t)__shfl((int)mine, base + m);
+        if ((pmask >> m) & 1u) smooth = __builtin_amdgcn_sad_u16(other, mine, smooth);
+    }
+    float e = 3.402823466e+38f;                                                 // FLT_MAX :580
+    if (inside) {
+        const float t = a.lambda_mult * (float)smooth;
+        e = (float)sad + t;                                                     // :607
+    }
+    // energies are >= 0, so their bit patterns order like the floats; absent lanes sort last
+    uint32_t ebits = present ? __float_as_uint(e) : 0xffffffffu;
+    uint32_t who = (uint32_t)k16;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        const uint32_t oe = (uint32_t)__shfl_xor((int)ebits, o), ow = (uint32_t)__shfl_xor((int)who, o);
+        if (oe < ebits || (oe == ebits && ow < who)) { ebits = oe; who = ow; }
+    }
+    return (mv_t)__shfl((int)mv, base + (int)who);
 }
 
 // ---- work-list state ---------------------------------------------------------------------
@@ -511,7 +559,7 @@ __global__ __launch_bounds__(256) void k_reg_pass1(RegArgs a)
 {
     constexpr int LPB = RegCfg<BS>::LPB;
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t == 0) { a.counters[0] = 0; a.counters[1] = 0; a.counters[2] = 0; a.counters[3] = 0; a.counters[4] = 0; a.counters[6] = 0; a.counters[7] = 0; a.counters[8] = 0; }
+    if (t == 0) { a.counters[0] = 0; a.counters[1] = 0; a.counters[2] = 0; a.counters[3] = 0; a.counters[4] = 0; a.counters[6] = 0; a.counters[7] = 0; a.counters[8] = 0; a.counters[9] = 0; a.counters[10] = 0; }
     const long long g = t / LPB;
     const int sub = (int)(t % LPB);
     if (g >= (long long)a.rows * a.cols) return;   // whole groups drop out together (LPB | 256)
@@ -543,7 +591,7 @@ __device__ __forceinline__ bool block_is_stale(const RegArgs &a, int r, int c)
 template <int BS>
 __device__ __forceinline__ void drain_lists(const RegArgs &a, int t, int nthreads)
 {
-    constexpr int LPB = RegCfg<BS>::LPB;
+    constexpr int LPB = 16;                      // lane k of a group = candidate k (eval_block_lanes)
     const int group = t / LPB, ngroups = nthreads / LPB, sub = t % LPB;
     // pass p reads list[p&1] (length counters[p%3]), appends to list[(p+1)&1] (counters[(p+1)%3])
     // and zeroes counters[(p+2)%3]; the overflow list of the solver is list0 / counters[1] -> p = 4.
@@ -568,7 +616,7 @@ __device__ __forceinline__ void drain_lists(const RegArgs &a, int t, int nthread
             const int r = (int)(x / a.cols), c = (int)(x % a.cols);
             if (sub == 0) own_release(a.own, x);                                  // the list owned it
             BBME_DRAIN();
-            const mv_t res = eval_block<BS, true>(a, r, c, sub, BBME_NEW_MASK);
+            const mv_t res = eval_block_lanes<BS, true>(a, r, c, sub, BBME_NEW_MASK);
             if (sub == 0 && res != load_est<true>(a.est + x)) {
                 __hip_atomic_store(a.est + x, res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 BBME_DRAIN();
@@ -590,8 +638,168 @@ __device__ __forceinline__ void drain_lists(const RegArgs &a, int t, int nthread
     }
 }
 
-// Asynchronous solver.  Every wave owns a private LDS queue.  It scans its share of the grid for
-// blocks that pass 1 left stale (64 blocks at a time), queues them, and whatever its own changes
+// =======================================================================================
+// K2, tile form.  One workgroup owns a tile of up to 32x32 blocks.  Old values and estimates of the
+// tile and of a one-block halo live in LDS, so following a change chain costs LDS latency plus one
+// (tile-local, mostly cached) image gather per round instead of several coherent memory trips.
+//   first launch of a sweep : pass 1 for every block of the tile (new := old), then the tile's own
+//                             fixed point, with the halo assumed unchanged (est = old);
+//   later launches          : only tiles whose flag carries this launch's epoch run; they reload the
+//                             halo (now holding their neighbours' results), re-evaluate every block
+//                             that has an input in the halo, and iterate to their fixed point again.
+// A tile whose border block ends a launch with a value different from the one its neighbours saw
+// stores epoch+1 into the flag of every tile that holds a dependant (R, DR, D, DL) of that block.
+// Rounds inside a tile are Jacobi steps: evaluate all queued blocks (reads only), barrier, apply the
+// changes and mark in-tile dependants dirty, barrier.  Whatever is still flagged after the last tile
+// launch is finished exactly by k_reg_solve, so the number of tile launches only affects speed.
+// =======================================================================================
+template <int BS>
+__global__ __launch_bounds__(256) void k_reg_tile(RegArgs a)
+{
+    constexpr int LPB = RegCfg<BS>::LPB;
+    constexpr int MAXT = 32, PIT = MAXT + 2;
+    __shared__ mv_t s_old[PIT * PIT], s_est[PIT * PIT], s_seen[PIT * PIT], s_res[MAXT * MAXT];
+    __shared__ uint16_t s_queue[MAXT * MAXT];
+    __shared__ uint8_t s_dirty[MAXT * MAXT];
+    __shared__ uint32_t s_qn;
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x;
+    if (!a.first && a.tile_flags[tile] != a.epoch) return;            // nobody touched this tile's halo
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int r0 = ty * a.tile_h, c0 = tx * a.tile_w;
+    const int h = min(a.tile_h, a.rows - r0), w = min(a.tile_w, a.cols - c0);
+    if (tid == 0) atomicAdd(&a.counters[9 + min((int)a.first ? 0 : 1, 1)], 1u);
+
+    // tile + halo into LDS
+    for (int i = tid; i < (h + 2) * (w + 2); i += 256) {
+        const int lr = i / (w + 2), lc = i - lr * (w + 2);
+        const int rr = r0 + lr - 1, cc = c0 + lc - 1;
+        const bool in = rr >= 0 && rr < a.rows && cc >= 0 && cc < a.cols;
+        mv_t o = 0, e = 0;
+        if (in) {
+            o = a.old_grid[(size_t)(rr >> a.old_shift) * a.old_cols + (cc >> a.old_shift)];
+            e = a.first ? o : a.est[(size_t)rr * a.cols + cc];
+        }
+        s_old[lr * PIT + lc] = o;
+        s_est[lr * PIT + lc] = e;
+        s_seen[lr * PIT + lc] = e;                                    // what the neighbours have seen of us
+    }
+    for (int i = tid; i < h * w; i += 256) s_dirty[i] = 0;
+    __syncthreads();
+
+    const int group = tid / LPB, ngroups = 256 / LPB, sub = tid % LPB;
+    // candidates of tile cell (lr, lc) (tile-local coordinates, 0-based inside the tile) from LDS
+    auto evaluate = [&](int lr, int lc, uint32_t use_new) -> mv_t {
+        const int r = r0 + lr, c = c0 + lc;
+        mv_t cand[9];
+        uint32_t present = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int rr = r + kNbRow[k], cc = c + kNbCol[k];
+            if (rr >= 0 && rr < a.rows && cc >= 0 && cc < a.cols) present |= 1u << k;
+            const int li = (lr + 1 + kNbRow[k]) * PIT + (lc + 1 + kNbCol[k]);
+            cand[k] = ((use_new >> k) & 1u) ? s_est[li] : s_old[li];
+        }
+        return score_block<BS>(a, cand, present, c * BS, r * BS, sub);
+    };
+
+    if (a.first) {
+        // pass 1: every block with new := old
+        for (int i = group; i < h * w; i += ngroups) {
+            const int lr = i / w, lc = i - lr * w;
+            const mv_t res = evaluate(lr, lc, 0u);
+            if (sub == 0) s_res[i] = res;
+        }
+        __syncthreads();
+        for (int i = tid; i < h * w; i += 256) {
+            const int lr = i / w, lc = i - lr * w;
+            s_est[(lr + 1) * PIT + lc + 1] = s_res[i];
+        }
+        __syncthreads();
+        // stale after pass 1: an already-updated input INSIDE the tile differs from its old value
+        for (int i = tid; i < h * w; i += 256) {
+            const int lr = i / w, lc = i - lr * w;
+            bool stale = false;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                if (!((BBME_NEW_MASK >> k) & 1u)) continue;
+                const int nr = lr + kNbRow[k], nc = lc + kNbCol[k];
+                if (nr < 0 || nr >= h || nc < 0 || nc >= w) continue;
+                const int li = (nr + 1) * PIT + nc + 1;
+                stale |= s_est[li] != s_old[li];
+            }
+            s_dirty[i] = stale;
+        }
+    } else {
+        // every block with an already-updated input in the halo: row 0 (UL, U, UR), column 0 (L, UL),
+        // last column (UR)
+        for (int i = tid; i < h * w; i += 256) {
+            const int lr = i / w, lc = i - lr * w;
+            s_dirty[i] = lr == 0 || lc == 0 || lc == w - 1;
+        }
+    }
+    __syncthreads();
+
+    // the tile's own fixed point.  A change travels along the raster dependency chain, shorter than
+    // 2h + w inside a tile; the cap is an exit every thread reaches together.
+    const int round_cap = 2 * h + w + 16;
+    for (int round = 0;; ++round) {
+        if (tid == 0) s_qn = 0;
+        __syncthreads();
+        for (int i = tid; i < h * w; i += 256)
+            if (s_dirty[i]) { s_dirty[i] = 0; s_queue[atomicAdd(&s_qn, 1u)] = (uint16_t)i; }
+        __syncthreads();
+        const int n = (int)s_qn;
+        if (n == 0) break;
+        if (round > round_cap) { if (tid == 0) a.counters[5] = 1; break; }
+        for (int qi = group; qi < n; qi += ngroups) {
+            const int i = s_queue[qi];
+            const int lr = i / w, lc = i - lr * w;
+            const mv_t res = evaluate(lr, lc, BBME_NEW_MASK);
+            if (sub == 0) s_res[i] = res;
+        }
+        __syncthreads();
+        for (int qi = tid; qi < n; qi += 256) {
+            const int i = s_queue[qi];
+            const int lr = i / w, lc = i - lr * w;
+            const mv_t res = s_res[i];
+            if (res != s_est[(lr + 1) * PIT + lc + 1]) {
+                s_est[(lr + 1) * PIT + lc + 1] = res;
+                const int dr[4] = {0, 1, 1, 1}, dc[4] = {1, 1, 0, -1};             // dependants R, DR, D, DL
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int nr = lr + dr[d], nc = lc + dc[d];
+                    if (nr < h && nc >= 0 && nc < w) s_dirty[nr * w + nc] = 1;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // write back, and tell the tiles that hold dependants of changed border blocks
+    for (int i = tid; i < h * w; i += 256) {
+        const int lr = i / w, lc = i - lr * w;
+        const int li = (lr + 1) * PIT + lc + 1;
+        const mv_t e = s_est[li];
+        const bool moved = e != s_seen[li];
+        if (a.first || moved) a.est[(size_t)(r0 + lr) * a.cols + c0 + lc] = e;
+        if (moved && (lr == h - 1 || lc == 0 || lc == w - 1)) {
+            const int dr[4] = {0, 1, 1, 1}, dc[4] = {1, 1, 0, -1};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int nr = lr + dr[d], nc = lc + dc[d];
+                if (nr < h && nc >= 0 && nc < w) continue;                         // inside this tile
+                const int rr = r0 + nr, cc = c0 + nc;
+                if (rr >= a.rows || cc < 0 || cc >= a.cols) continue;
+                a.tile_flags[(rr / a.tile_h) * a.tiles_x + cc / a.tile_w] = a.epoch + 1;
+            }
+        }
+    }
+}
+
+// Asynchronous solver (the exact finisher).  Every wave owns a private LDS queue.  It scans its share
+// of the grid for blocks that may still be inconsistent (after k_reg_tile: blocks with an input in the
+// halo of a tile that is still flagged; after k_reg_pass1: blocks pass 1 left stale), queues them, and whatever its own changes
 // make stale it queues locally too and evaluates itself, round after round, without any grid-wide
 // step: fixed-point iteration tolerates any evaluation order.  A wave whose queue is empty and
 // which has scanned its share simply exits.  If a local queue is full the surplus goes to a
@@ -600,8 +808,12 @@ __device__ __forceinline__ void drain_lists(const RegArgs &a, int t, int nthread
 template <int BS>
 __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
 {
-    constexpr int LPB = RegCfg<BS>::LPB;
-    constexpr int NB = 64 / LPB;                 // blocks evaluated per wave per round
+    // two forms of a round: WIDE (eval_block: LPBW lanes per block, 64/LPBW blocks per round) when
+    // the queue is long and throughput counts, LANES (eval_block_lanes: 16 lanes per block, lane k =
+    // candidate k, 4 blocks per round) when it is short and the wave is walking a chain
+    constexpr int LPBW = RegCfg<BS>::LPB;
+    constexpr int NBW = 64 / LPBW;
+    constexpr int NBL = 4;
     constexpr uint32_t QCAP = 1024;
     __shared__ uint32_t qmem[4][QCAP];
     __shared__ uint32_t s_ticket;
@@ -612,7 +824,6 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
     const uint32_t nblocks = (uint32_t)a.rows * a.cols;
     uint32_t *ovf_list = a.list0;
     uint32_t *ovf_count = &a.counters[1];
-    const int g = lane / LPB, sub = lane % LPB;
     uint32_t head = 0, tail = 0;                  // wave-uniform, free-running
     uint32_t evaluated = 0, rounds = 0;
     // every round either empties part of the queue or follows a real change; the cap is only an
@@ -635,20 +846,34 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
 
     // scan granularity: two rounds' worth of blocks, so that a cluster of stale blocks is spread
     // over many waves instead of queueing up behind one
-    constexpr uint32_t SCAN = (2 * NB < 64) ? 2 * NB : 64;
+    constexpr uint32_t SCAN = 16;
     for (uint32_t base = w * SCAN;; base += W * SCAN) {
         if (base < nblocks) {
             const uint32_t x = base + lane;
             bool mine = false;
-            if ((uint32_t)lane < SCAN && x < nblocks && block_is_stale(a, (int)(x / a.cols), (int)(x % a.cols)))
-                mine = own_claim(a.own, x) == 0;
+            if ((uint32_t)lane < SCAN && x < nblocks) {
+                const int r = (int)(x / a.cols), c = (int)(x % a.cols);
+                bool suspect;
+                if (a.tile_flags) {
+                    // after the tile launches: blocks with an input in the halo of a tile that is still flagged
+                    const int lr = r % a.tile_h, lc = c % a.tile_w;
+                    suspect = a.tile_flags[(r / a.tile_h) * a.tiles_x + c / a.tile_w] == a.epoch &&
+                              (lr == 0 || lc == 0 || lc == a.tile_w - 1 || c == a.cols - 1);
+                } else {
+                    suspect = block_is_stale(a, r, c);                  // directly after k_reg_pass1
+                }
+                if (suspect) mine = own_claim(a.own, x) == 0;
+            }
             enqueue(mine, x);
         } else if (head == tail) {
             break;
         }
         while (head != tail) {
             if (++rounds > round_cap) { if (lane == 0) a.counters[5] = 1; head = tail; break; }
-            const uint32_t cnt = min((uint32_t)NB, tail - head);
+            const bool wide = NBW > NBL && tail - head > (uint32_t)NBL;   // wave-uniform
+            const int gl = wide ? LPBW : 16;                             // lanes per block this round
+            const int g = lane / gl, sub = lane % gl;
+            const uint32_t cnt = min((uint32_t)(wide ? NBW : NBL), tail - head);
             const bool active = (uint32_t)g < cnt;
             const uint32_t x = active ? q[(head + g) % QCAP] : 0u;      // owned since it was claimed
             head = __builtin_amdgcn_readfirstlane(head + cnt);
@@ -659,7 +884,9 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
                 r = (int)(x / a.cols); c = (int)(x % a.cols);
                 mv_t prev = 0;
                 if (leader) prev = load_est<true>(a.est + x);          // issued with the candidate loads
-                const mv_t res = eval_block<BS, true>(a, r, c, sub, BBME_NEW_MASK);
+                mv_t res;
+                if (wide) res = eval_block<BS, true>(a, r, c, sub, BBME_NEW_MASK);
+                else res = eval_block_lanes<BS, true>(a, r, c, sub, BBME_NEW_MASK);
                 changed = leader && res != prev;
                 if (changed) __hip_atomic_store(a.est + x, res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -785,6 +1012,23 @@ __global__ __launch_bounds__(256) void k_calib_read_dword(const uint32_t *p, siz
 // =======================================================================================
 // instruction probes (bbme_selftest_isa)
 // =======================================================================================
+// unaligned global loads: dword / dwordx2 / dwordx4 at arbitrary byte addresses
+struct __attribute__((packed, aligned(1))) ua_u32 { uint32_t v; };
+struct __attribute__((packed, aligned(1))) ua_u32x2 { uint32_t v[2]; };
+struct __attribute__((packed, aligned(1))) ua_u32x4 { uint32_t v[4]; };
+__global__ void k_probe_unaligned(const uint8_t *p, uint32_t *out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *q = p + 5 * i + (i & 3);                  // every byte alignment occurs
+    const uint32_t a = reinterpret_cast<const ua_u32 *>(q)->v;
+    const ua_u32x2 b = *reinterpret_cast<const ua_u32x2 *>(q + 1);
+    const ua_u32x4 c = *reinterpret_cast<const ua_u32x4 *>(q + 2);
+    out[7 * i + 0] = a;
+    out[7 * i + 1] = b.v[0]; out[7 * i + 2] = b.v[1];
+    out[7 * i + 3] = c.v[0]; out[7 * i + 4] = c.v[1]; out[7 * i + 5] = c.v[2]; out[7 * i + 6] = c.v[3];
+}
+
 __global__ void k_probe_sad(const uint32_t *a, const uint32_t *b, const uint32_t *c,
                             uint32_t *sad_out, unsigned long long *qsad_out, uint32_t *align_out,
                             uint32_t *sad16_out, int n)

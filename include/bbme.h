@@ -158,8 +158,9 @@ int bbme_get_timings(bbme_ctx *ctx, float *total_ms, float *search_ms, float *re
 int bbme_calibrate_read(int device, unsigned mbytes, int repeats);
 
 /* Instruction probes used by the GPU test-suite: checks v_sad_u8, v_alignbyte_b32,
- * v_qsad_pk_u16_u8 and v_sad_u16 against a scalar model on 65536 random operands.
- * mismatches[0..3] receive the number of disagreements per instruction, in that order. */
+ * v_qsad_pk_u16_u8 and v_sad_u16 against a scalar model on 65536 random operands, and unaligned
+ * dword / dwordx2 / dwordx4 global loads against byte-assembled values.
+ * mismatches[0..4] receive the number of disagreements per item, in that order. */
 int bbme_selftest_isa(int device, int *mismatches);
 
 #ifdef __cplusplus

@@ -14,9 +14,9 @@ def test_isa_probes(bbme):
     """v_sad_u8 / v_alignbyte_b32 / v_qsad_pk_u16_u8 / v_sad_u16 behave as the kernels assume."""
     import ctypes as C
     from blockbasedmotionestimation_amd import _capi
-    mism = (C.c_int * 4)()
+    mism = (C.c_int * 5)()
     _capi.check(_capi.lib().bbme_selftest_isa(0, mism))
-    assert list(mism) == [0, 0, 0, 0], "sad_u8, alignbyte, qsad_pk_u16_u8, sad_u16 mismatches: %s" % list(mism)
+    assert list(mism) == [0] * 5, "sad_u8, alignbyte, qsad_pk_u16_u8, sad_u16, unaligned loads: %s" % list(mism)
 
 
 CASES = [
