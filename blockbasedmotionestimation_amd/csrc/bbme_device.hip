@@ -731,6 +731,35 @@ int bbme_get_timings(bbme_ctx *c, float *total, float *search, float *reg, float
     return BBME_OK;
 }
 
+int bbme_probe_rates(int device, double *gops)
+{
+    if (!gops) return bbme::fail(BBME_ERR_INVALID, "null output");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return bbme::fail(BBME_ERR_HIP, "no HIP device %d", device);
+    HIP_TRY(hipSetDevice(device));
+    uint32_t *out = nullptr;
+    HIP_TRY(hipMalloc(&out, 64));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    const int iters = 4096, grid = 256 * 8;          // 8 workgroups of 4 waves per CU: 8 waves per SIMD
+    for (int which = 0; which < 2; ++which) {
+        for (int rep = 0; rep < 2; ++rep) {
+            HIP_TRY(hipEventRecord(e0, 0));
+            if (which == 0) hipLaunchKernelGGL(k_probe_rate<0>, dim3(grid), dim3(256), 0, 0, out, iters, 7u + rep);
+            else hipLaunchKernelGGL(k_probe_rate<1>, dim3(grid), dim3(256), 0, 0, out, iters, 7u + rep);
+            HIP_TRY(hipEventRecord(e1, 0));
+            HIP_TRY(hipEventSynchronize(e1));
+        }
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        // wave-instructions per second over the whole chip, in units of 1e9
+        gops[which] = (double)grid * 4 * iters * 8 / (ms * 1e-3) / 1e9;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(out);
+    return BBME_OK;
+}
+
 int bbme_calibrate_read(int device, unsigned mbytes, int repeats)
 {
     int ndev = 0;

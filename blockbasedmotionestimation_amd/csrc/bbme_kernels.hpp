@@ -1012,6 +1012,34 @@ __global__ __launch_bounds__(256) void k_calib_read_dword(const uint32_t *p, siz
 // =======================================================================================
 // instruction probes (bbme_selftest_isa)
 // =======================================================================================
+// issue-rate probes: 8 independent accumulator chains per lane, ITER x 8 instructions per lane
+template <int WHICH>
+__global__ __launch_bounds__(256) void k_probe_rate(uint32_t *out, int iters, uint32_t seed)
+{
+    uint32_t x = seed + threadIdx.x;
+    if constexpr (WHICH == 0) {
+        unsigned long long acc[8];
+        for (int i = 0; i < 8; ++i) acc[i] = x + i;
+        const unsigned long long pair = ((unsigned long long)(x * 2654435761u) << 32) | (x * 40503u);
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_qsad_pk_u16_u8(pair, x + i, acc[i]);
+        unsigned long long r = 0;
+        for (int i = 0; i < 8; ++i) r ^= acc[i];
+        if (r == 0x123456789abcdefull) out[0] = 1;
+    } else {
+        uint32_t acc[8];
+        for (int i = 0; i < 8; ++i) acc[i] = x + i;
+        const uint32_t w = x * 2654435761u;
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_sad_u8(w, x + i, acc[i]);
+        uint32_t r = 0;
+        for (int i = 0; i < 8; ++i) r ^= acc[i];
+        if (r == 0x12345678u) out[0] = 1;
+    }
+}
+
 // unaligned global loads: dword / dwordx2 / dwordx4 at arbitrary byte addresses
 struct __attribute__((packed, aligned(1))) ua_u32 { uint32_t v; };
 struct __attribute__((packed, aligned(1))) ua_u32x2 { uint32_t v[2]; };

@@ -152,6 +152,11 @@ int bbme_set_profiling(bbme_ctx *ctx, int enabled);
 int bbme_get_timings(bbme_ctx *ctx, float *total_ms, float *search_ms, float *regularize_ms,
                      float *expand_ms, float *search_level0_ms);
 
+/* Measures the chip-wide issue rate of v_qsad_pk_u16_u8 (gops[0]) and v_sad_u8 (gops[1]) in 1e9
+ * wave-instructions per second (8 waves per SIMD, 8 independent chains per lane): the VALU
+ * ceilings bench.py prices the search kernel against. */
+int bbme_probe_rates(int device, double *gops);
+
 /* Profiling aid: launches a kernel that reads `mbytes` MiB exactly once with one aligned dword per
  * lane (the access shape of the search kernel's window staging), `repeats` times, so that the
  * FETCH_SIZE counter can be calibrated against a known byte count in the same rocprofv3 run. */
