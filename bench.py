@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-iters", type=int, default=5)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal on one GPU: run the N>1 code path (process group, gather, expand) with world size 1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -97,8 +99,10 @@ def main():
     import blockbasedmotionestimation_amd as bbme
 
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
@@ -111,25 +115,35 @@ def main():
     pw, ph = mf.padded_width, mf.padded_height
     blocks = level_blocks(pw, ph, block, levels)
 
-    # dense result as a torch view (for the gather); the ctx owns the memory
-    class _View:
-        pass
-    v = _View()
-    v.__cuda_array_interface__ = {"shape": (ph, pw, 2), "typestr": "<f4", "data": (mf.flow_device_ptr(), False),
-                                  "version": 2, "strides": None}
-    flow_t = torch.as_tensor(v, device=torch.device("cuda", local_rank))
-    gather_list = [torch.empty_like(flow_t) for _ in range(world)] if (world > 1 and rank == 0) else None
-    compute_done = torch.cuda.Event()
+    # Multi-GPU: everything runs on torch's current stream (one order for kernels and collectives).
+    # Each rank's result travels as the compact cell grid -- one int16 (dx, dy) pair per 2x2 cell,
+    # 4.2 MB at 4K, exactly the information of the dense field -- and rank 0 expands every gathered
+    # grid to the dense .flo field with the expand kernel (copy_to_all_pixels).
+    def device_view(ptr, shape, typestr):
+        class _View:
+            pass
+        v = _View()
+        v.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2, "strides": None}
+        return torch.as_tensor(v, device=torch.device("cuda", local_rank))
+
+    gather_list = flows = None
+    if use_dist:
+        mf.set_stream(torch.cuda.current_stream().cuda_stream)
+        cells_t = device_view(mf.cells_device_ptr(), (ph // 2, pw // 2), "<i4")     # packed int16 (dx, dy); NCCL has no int16
+        if rank == 0:
+            gather_list = [torch.empty_like(cells_t) for _ in range(world)]
+            flows = torch.empty((world, ph, pw, 2), dtype=torch.float32, device=cells_t.device)
 
     def step():
-        mf.estimate_async()                       # whole pyramid on the ctx stream, no host wait
-        if world > 1:
-            # hand the finished field to the current torch stream, gather the .flo fields on rank 0
-            mf.synchronize()
-            dist.gather(flow_t, gather_list, dst=0)
+        mf.estimate_async()                       # whole pyramid, no host wait
+        if use_dist:
+            dist.gather(cells_t, gather_list, dst=0)
+            if rank == 0:
+                for r in range(world):
+                    mf.expand_cells_device(gather_list[r].data_ptr(), flows[r].data_ptr())
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         mf.synchronize()
         torch.cuda.synchronize()
@@ -142,12 +156,15 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     result_flow = mf.get_flow() if rank == 0 else None
+    if use_dist and rank == 0:
+        # the field rank 0 expanded from its own gathered cells must be the field its context holds
+        assert np.array_equal(flows[0].cpu().numpy(), result_flow), "gathered + expanded field differs"
 
     # per-kernel timing with HIP events on the ctx stream (eager launches, same kernels and data)
     prof = None
@@ -187,7 +204,8 @@ def main():
             "config": {"workload": desc, "pairs_per_step": world, "frame": [w, h], "padded": [pw, ph],
                        "block": block, "search_range": R, "levels": levels,
                        "blocks_level0": blocks[0], "blocks_all_levels": sum(blocks),
-                       "multi_gpu": "one pair per GPU, dense flow gathered to rank 0 (RCCL)" if world > 1 else "single GPU"},
+                       "multi_gpu": ("one pair per GPU; int16 cell grids gathered on rank 0 over RCCL and expanded "
+                                     "there to the dense .flo fields") if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_search_fast<%d> (mean of the %d per-level launches)" % (block, levels),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(levels),
@@ -210,7 +228,7 @@ def main():
             out["parity_vs_oracle"] = parity
         print(json.dumps(out))
     mf.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

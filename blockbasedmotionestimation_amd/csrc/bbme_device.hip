@@ -625,6 +625,29 @@ int bbme_get_cells_host(bbme_ctx *c, int16_t *cells)
     return BBME_OK;
 }
 
+int bbme_cells_device(bbme_ctx *c, const int16_t **d_cells)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (!d_cells) return bbme::fail(BBME_ERR_INVALID, "null output");
+    // two sweeps per block size leave the final field of every level in grid[0] (see bbme_estimate)
+    *d_cells = reinterpret_cast<const int16_t *>(c->lv[0].grid[0]);
+    return BBME_OK;
+}
+
+int bbme_expand_cells_device(bbme_ctx *c, const int16_t *d_cells, float *d_flow)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (!d_cells || !d_flow) return bbme::fail(BBME_ERR_INVALID, "null pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    Level &L = c->lv[0];
+    const int cc = L.width / 2, cr = L.height / 2;
+    const long long threads = (long long)cc * cr * 2;
+    hipLaunchKernelGGL(k_expand, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream,
+                       reinterpret_cast<const mv_t *>(d_cells), cc, cr, d_flow, L.width);
+    HIP_TRY(hipGetLastError());
+    return BBME_OK;
+}
+
 int bbme_stage_search(bbme_ctx *c, int level)
 {
     if (int rc = check_level(c, level)) return rc;

@@ -124,6 +124,15 @@ class MF:
         _capi.check(self._lib.bbme_flow_device(self._ctx, C.byref(p)))
         return p.value
 
+    def cells_device_ptr(self):
+        p = C.c_void_p()
+        _capi.check(self._lib.bbme_cells_device(self._ctx, C.byref(p)))
+        return p.value
+
+    def expand_cells_device(self, cells_ptr, flow_ptr):
+        """copy_to_all_pixels for a cell grid anywhere in HBM -> dense padded field (device pointers)."""
+        _capi.check(self._lib.bbme_expand_cells_device(self._ctx, C.c_void_p(cells_ptr), C.c_void_p(flow_ptr)))
+
     def calcMotionBlockMatching(self):
         """cv::Mat MF::calcMotionBlockMatching() -- dense padded (H, W, 2) float32 (u, v) field."""
         self.estimate_async()

@@ -120,6 +120,10 @@ int bbme_flow_device(bbme_ctx *ctx, const float **d_flow);
 /* Synchronises, then copies the dense padded field to the host. */
 int bbme_get_flow_host(bbme_ctx *ctx, float *flow /* padded_h * padded_w * 2 */);
 /* Compact result: one int16 (dx,dy) pair per 2x2 cell of level 0 ((H0/2) x (W0/2)). */
+int bbme_cells_device(bbme_ctx *ctx, const int16_t **d_cells);
+/* copy_to_all_pixels (:815-826) for a cell grid that lives anywhere in HBM (e.g. gathered from
+ * another GPU): writes the dense padded H0 x W0 float2 field to d_flow, on the ctx stream. */
+int bbme_expand_cells_device(bbme_ctx *ctx, const int16_t *d_cells, float *d_flow);
 int bbme_get_cells_host(bbme_ctx *ctx, int16_t *cells);
 
 /* ---- single stages, for parity tests against the reference's private methods -------- */

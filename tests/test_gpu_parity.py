@@ -125,6 +125,13 @@ def test_full_pipeline_host_frames(bbme, oracle):
     assert np.array_equal(mf.calcMotionBlockMatching(), exp)
     cells = mf.get_cells()
     assert np.array_equal(cells.astype(np.float32), exp[::2, ::2])
+    # the multi-GPU path: a cell grid copied elsewhere in HBM (as after a gather) expands to the same field
+    import torch
+    moved = torch.from_numpy(cells.copy()).cuda()
+    dense = torch.zeros((448, 640, 2), dtype=torch.float32, device="cuda")
+    mf.expand_cells_device(moved.data_ptr(), dense.data_ptr())
+    mf.synchronize()
+    assert np.array_equal(dense.cpu().numpy(), exp)
     assert np.array_equal(np.repeat(np.repeat(cells, 2, 0), 2, 1).astype(np.float32), exp)
     mf.close()
 
