@@ -60,12 +60,6 @@ struct bbme_ctx {
     uint8_t *raw[2] = {nullptr, nullptr};         // unpadded frames for bbme_set_frames_device staging
     bool frames_set = false;
     int solve_wgs = 1280;                         // most workgroups of k_reg_solve (4 independent waves each)
-    int tile_launches = 0;                        // k_reg_tile launches per sweep (0 = plain pass1 + solve); BBME_TILE_LAUNCHES
-    int tile_max_block = 64;                      // tile form only for block sizes <= this; BBME_TILE_MAX_BLOCK
-    int tile_mult1_only = 0;                      // tile form only for the first sweep of a block size; BBME_TILE_MULT1
-    int tile_size = 0;                            // tile edge in blocks (0 = pick per grid); BBME_TILE_SIZE
-    uint32_t *tile_flags = nullptr;
-    uint32_t epoch = 16;
     bool force_generic_search = false;            // BBME_GENERIC_SEARCH=1: use k_search_generic everywhere
     bool use_graph = true;
     hipGraphExec_t graph_exec = nullptr;
@@ -167,36 +161,14 @@ int launch_search(bbme_ctx *c, int level)
 }
 
 template <int BS>
-void launch_sweep_t(RegArgs a, int max_solve_wgs, int tile_launches, int tile_size, uint32_t epoch0, hipStream_t s)
+void launch_sweep_t(const RegArgs &a, int max_solve_wgs, hipStream_t s)
 {
     constexpr int LPB = RegCfg<BS>::LPB;
     const long long blocks = (long long)a.rows * a.cols;
-    // every solver wave scans 64 blocks per step; more workgroups than that would find nothing
-    const int grid2 = (int)std::min<long long>(max_solve_wgs, (blocks + 255) / 256);
-    if (tile_launches <= 0) {
-        // plain form: pass 1 over the whole grid, then the asynchronous solver
-        const int grid1 = (int)((blocks * LPB + 255) / 256);
-        a.tile_flags = nullptr;
-        hipLaunchKernelGGL(k_reg_pass1<BS>, dim3(grid1), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(k_reg_solve<BS>, dim3(grid2), dim3(256), 0, s, a);
-        return;
-    }
-    // tile form: tiles as large as possible while there are still enough of them to fill the chip
-    int t = tile_size;
-    if (t <= 0) {
-        t = 32;
-        while (t > 8 && ((a.rows + t - 1) / t) * (long long)((a.cols + t - 1) / t) < 1024) t >>= 1;
-    }
-    a.tile_h = t; a.tile_w = t;
-    a.tiles_x = (a.cols + t - 1) / t;
-    const int ntiles = a.tiles_x * ((a.rows + t - 1) / t);
-    for (int k = 0; k < tile_launches; ++k) {
-        a.epoch = epoch0 + k;
-        a.first = k == 0;
-        hipLaunchKernelGGL(k_reg_tile<BS>, dim3(ntiles), dim3(256), 0, s, a);
-    }
-    a.epoch = epoch0 + tile_launches;
-    a.first = 0;
+    const int grid1 = (int)((blocks * LPB + 255) / 256);
+    // every solver wave scans 16 blocks per step; more workgroups than that would find nothing
+    const int grid2 = (int)std::min<long long>(max_solve_wgs, (blocks + 63) / 64);
+    hipLaunchKernelGGL(k_reg_pass1<BS>, dim3(grid1), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_reg_solve<BS>, dim3(grid2), dim3(256), 0, s, a);
 }
 
@@ -226,17 +198,13 @@ int launch_sweep(bbme_ctx *c, int level, int b, int mult)
     a.list0 = c->list[0]; a.list1 = c->list[1];
     a.own = c->own;
     a.counters = c->counters;
-    a.tile_flags = c->tile_flags;
-    c->epoch += 16;                       // epochs of one sweep's launches: epoch .. epoch + tile_launches
-    const uint32_t e0 = c->epoch;
-    const int tl = (b <= c->tile_max_block && (!c->tile_mult1_only || mult == 1)) ? c->tile_launches : 0;
     switch (b) {
-    case 2:  launch_sweep_t<2>(a, c->solve_wgs, tl, c->tile_size, e0, c->stream); break;
-    case 4:  launch_sweep_t<4>(a, c->solve_wgs, tl, c->tile_size, e0, c->stream); break;
-    case 8:  launch_sweep_t<8>(a, c->solve_wgs, tl, c->tile_size, e0, c->stream); break;
-    case 16: launch_sweep_t<16>(a, c->solve_wgs, tl, c->tile_size, e0, c->stream); break;
-    case 32: launch_sweep_t<32>(a, c->solve_wgs, tl, c->tile_size, e0, c->stream); break;
-    case 64: launch_sweep_t<64>(a, c->solve_wgs, tl, c->tile_size, e0, c->stream); break;
+    case 2:  launch_sweep_t<2>(a, c->solve_wgs, c->stream); break;
+    case 4:  launch_sweep_t<4>(a, c->solve_wgs, c->stream); break;
+    case 8:  launch_sweep_t<8>(a, c->solve_wgs, c->stream); break;
+    case 16: launch_sweep_t<16>(a, c->solve_wgs, c->stream); break;
+    case 32: launch_sweep_t<32>(a, c->solve_wgs, c->stream); break;
+    case 64: launch_sweep_t<64>(a, c->solve_wgs, c->stream); break;
     default: return bbme::fail(BBME_ERR_UNSUPPORTED, "block size %d", b);
     }
     HIP_TRY(hipGetLastError());
@@ -345,10 +313,6 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
     c->params = *params; c->geom = g; c->device = device;
     if (const char *e = getenv("BBME_SOLVE_WGS")) c->solve_wgs = std::max(1, std::min(8192, atoi(e)));
     if (const char *e = getenv("BBME_NO_GRAPH")) c->use_graph = atoi(e) == 0;
-    if (const char *e = getenv("BBME_TILE_LAUNCHES")) c->tile_launches = std::max(0, std::min(8, atoi(e)));
-    if (const char *e = getenv("BBME_TILE_MAX_BLOCK")) c->tile_max_block = atoi(e);
-    if (const char *e = getenv("BBME_TILE_MULT1")) c->tile_mult1_only = atoi(e);
-    if (const char *e = getenv("BBME_TILE_SIZE")) { int v = atoi(e); c->tile_size = (v == 8 || v == 16 || v == 32) ? v : 0; }
     if (const char *e = getenv("BBME_GENERIC_SEARCH")) c->force_generic_search = atoi(e) != 0;
     c->lv.resize(nl);
     auto cleanup_fail = [&](int rc) { bbme_destroy(c); return rc; };
@@ -402,8 +366,6 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
         (err = hipMalloc(&c->list[1], max_blocks * 4)) != hipSuccess ||
         (err = hipMalloc(&c->own, bit_words * 4)) != hipSuccess ||
         (err = hipMalloc(&c->counters, 64)) != hipSuccess ||
-        (err = hipMalloc(&c->tile_flags, (max_blocks / 64 + 1024) * 4)) != hipSuccess ||
-        (err = hipMemset(c->tile_flags, 0, (max_blocks / 64 + 1024) * 4)) != hipSuccess ||
         (err = hipMalloc(&c->raw[0], raw_bytes)) != hipSuccess ||
         (err = hipMalloc(&c->raw[1], raw_bytes)) != hipSuccess ||
         (err = hipMemset(c->own, 0, bit_words * 4)) != hipSuccess ||
@@ -430,7 +392,6 @@ int bbme_destroy(bbme_ctx *c)
     (void)hipFree(c->flow);
     (void)hipFree(c->list[0]); (void)hipFree(c->list[1]);
     (void)hipFree(c->own);
-    (void)hipFree(c->tile_flags);
     (void)hipFree(c->counters);
     (void)hipFree(c->raw[0]); (void)hipFree(c->raw[1]);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);

@@ -338,11 +338,6 @@ struct RegArgs {
     // work lists
     uint32_t *list0, *list1;    // block indices
     uint32_t *own;              // ownership counters, 16 bits per block (see "work-list state" below)
-    // tiling of the grid (k_reg_tile) and the epoch flags with which tiles notify their neighbours
-    int tile_h, tile_w, tiles_x;
-    uint32_t *tile_flags;       // [tile] = epoch of the launch that must look at the tile again
-    uint32_t epoch;             // epoch of this launch
-    int first;                  // k_reg_tile: 1 = first launch of the sweep (pass 1 for every tile)
     uint32_t *counters;         // [0..2] list lengths (rotating), [3] safety-net passes, [4] blocks re-evaluated,
                                 // [5] sticky: a sweep hit a cap without converging, [6] solver ticket
 };
@@ -559,7 +554,7 @@ __global__ __launch_bounds__(256) void k_reg_pass1(RegArgs a)
 {
     constexpr int LPB = RegCfg<BS>::LPB;
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t == 0) { a.counters[0] = 0; a.counters[1] = 0; a.counters[2] = 0; a.counters[3] = 0; a.counters[4] = 0; a.counters[6] = 0; a.counters[7] = 0; a.counters[8] = 0; a.counters[9] = 0; a.counters[10] = 0; }
+    if (t == 0) { a.counters[0] = 0; a.counters[1] = 0; a.counters[2] = 0; a.counters[3] = 0; a.counters[4] = 0; a.counters[6] = 0; a.counters[7] = 0; a.counters[8] = 0; }
     const long long g = t / LPB;
     const int sub = (int)(t % LPB);
     if (g >= (long long)a.rows * a.cols) return;   // whole groups drop out together (LPB | 256)
@@ -638,168 +633,8 @@ __device__ __forceinline__ void drain_lists(const RegArgs &a, int t, int nthread
     }
 }
 
-// =======================================================================================
-// K2, tile form.  One workgroup owns a tile of up to 32x32 blocks.  Old values and estimates of the
-// tile and of a one-block halo live in LDS, so following a change chain costs LDS latency plus one
-// (tile-local, mostly cached) image gather per round instead of several coherent memory trips.
-//   first launch of a sweep : pass 1 for every block of the tile (new := old), then the tile's own
-//                             fixed point, with the halo assumed unchanged (est = old);
-//   later launches          : only tiles whose flag carries this launch's epoch run; they reload the
-//                             halo (now holding their neighbours' results), re-evaluate every block
-//                             that has an input in the halo, and iterate to their fixed point again.
-// A tile whose border block ends a launch with a value different from the one its neighbours saw
-// stores epoch+1 into the flag of every tile that holds a dependant (R, DR, D, DL) of that block.
-// Rounds inside a tile are Jacobi steps: evaluate all queued blocks (reads only), barrier, apply the
-// changes and mark in-tile dependants dirty, barrier.  Whatever is still flagged after the last tile
-// launch is finished exactly by k_reg_solve, so the number of tile launches only affects speed.
-// =======================================================================================
-template <int BS>
-__global__ __launch_bounds__(256) void k_reg_tile(RegArgs a)
-{
-    constexpr int LPB = RegCfg<BS>::LPB;
-    constexpr int MAXT = 32, PIT = MAXT + 2;
-    __shared__ mv_t s_old[PIT * PIT], s_est[PIT * PIT], s_seen[PIT * PIT], s_res[MAXT * MAXT];
-    __shared__ uint16_t s_queue[MAXT * MAXT];
-    __shared__ uint8_t s_dirty[MAXT * MAXT];
-    __shared__ uint32_t s_qn;
-    const int tid = threadIdx.x;
-    const int tile = blockIdx.x;
-    if (!a.first && a.tile_flags[tile] != a.epoch) return;            // nobody touched this tile's halo
-    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-    const int r0 = ty * a.tile_h, c0 = tx * a.tile_w;
-    const int h = min(a.tile_h, a.rows - r0), w = min(a.tile_w, a.cols - c0);
-    if (tid == 0) atomicAdd(&a.counters[9 + min((int)a.first ? 0 : 1, 1)], 1u);
-
-    // tile + halo into LDS
-    for (int i = tid; i < (h + 2) * (w + 2); i += 256) {
-        const int lr = i / (w + 2), lc = i - lr * (w + 2);
-        const int rr = r0 + lr - 1, cc = c0 + lc - 1;
-        const bool in = rr >= 0 && rr < a.rows && cc >= 0 && cc < a.cols;
-        mv_t o = 0, e = 0;
-        if (in) {
-            o = a.old_grid[(size_t)(rr >> a.old_shift) * a.old_cols + (cc >> a.old_shift)];
-            e = a.first ? o : a.est[(size_t)rr * a.cols + cc];
-        }
-        s_old[lr * PIT + lc] = o;
-        s_est[lr * PIT + lc] = e;
-        s_seen[lr * PIT + lc] = e;                                    // what the neighbours have seen of us
-    }
-    for (int i = tid; i < h * w; i += 256) s_dirty[i] = 0;
-    __syncthreads();
-
-    const int group = tid / LPB, ngroups = 256 / LPB, sub = tid % LPB;
-    // candidates of tile cell (lr, lc) (tile-local coordinates, 0-based inside the tile) from LDS
-    auto evaluate = [&](int lr, int lc, uint32_t use_new) -> mv_t {
-        const int r = r0 + lr, c = c0 + lc;
-        mv_t cand[9];
-        uint32_t present = 0;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const int rr = r + kNbRow[k], cc = c + kNbCol[k];
-            if (rr >= 0 && rr < a.rows && cc >= 0 && cc < a.cols) present |= 1u << k;
-            const int li = (lr + 1 + kNbRow[k]) * PIT + (lc + 1 + kNbCol[k]);
-            cand[k] = ((use_new >> k) & 1u) ? s_est[li] : s_old[li];
-        }
-        return score_block<BS>(a, cand, present, c * BS, r * BS, sub);
-    };
-
-    if (a.first) {
-        // pass 1: every block with new := old
-        for (int i = group; i < h * w; i += ngroups) {
-            const int lr = i / w, lc = i - lr * w;
-            const mv_t res = evaluate(lr, lc, 0u);
-            if (sub == 0) s_res[i] = res;
-        }
-        __syncthreads();
-        for (int i = tid; i < h * w; i += 256) {
-            const int lr = i / w, lc = i - lr * w;
-            s_est[(lr + 1) * PIT + lc + 1] = s_res[i];
-        }
-        __syncthreads();
-        // stale after pass 1: an already-updated input INSIDE the tile differs from its old value
-        for (int i = tid; i < h * w; i += 256) {
-            const int lr = i / w, lc = i - lr * w;
-            bool stale = false;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                if (!((BBME_NEW_MASK >> k) & 1u)) continue;
-                const int nr = lr + kNbRow[k], nc = lc + kNbCol[k];
-                if (nr < 0 || nr >= h || nc < 0 || nc >= w) continue;
-                const int li = (nr + 1) * PIT + nc + 1;
-                stale |= s_est[li] != s_old[li];
-            }
-            s_dirty[i] = stale;
-        }
-    } else {
-        // every block with an already-updated input in the halo: row 0 (UL, U, UR), column 0 (L, UL),
-        // last column (UR)
-        for (int i = tid; i < h * w; i += 256) {
-            const int lr = i / w, lc = i - lr * w;
-            s_dirty[i] = lr == 0 || lc == 0 || lc == w - 1;
-        }
-    }
-    __syncthreads();
-
-    // the tile's own fixed point.  A change travels along the raster dependency chain, shorter than
-    // 2h + w inside a tile; the cap is an exit every thread reaches together.
-    const int round_cap = 2 * h + w + 16;
-    for (int round = 0;; ++round) {
-        if (tid == 0) s_qn = 0;
-        __syncthreads();
-        for (int i = tid; i < h * w; i += 256)
-            if (s_dirty[i]) { s_dirty[i] = 0; s_queue[atomicAdd(&s_qn, 1u)] = (uint16_t)i; }
-        __syncthreads();
-        const int n = (int)s_qn;
-        if (n == 0) break;
-        if (round > round_cap) { if (tid == 0) a.counters[5] = 1; break; }
-        for (int qi = group; qi < n; qi += ngroups) {
-            const int i = s_queue[qi];
-            const int lr = i / w, lc = i - lr * w;
-            const mv_t res = evaluate(lr, lc, BBME_NEW_MASK);
-            if (sub == 0) s_res[i] = res;
-        }
-        __syncthreads();
-        for (int qi = tid; qi < n; qi += 256) {
-            const int i = s_queue[qi];
-            const int lr = i / w, lc = i - lr * w;
-            const mv_t res = s_res[i];
-            if (res != s_est[(lr + 1) * PIT + lc + 1]) {
-                s_est[(lr + 1) * PIT + lc + 1] = res;
-                const int dr[4] = {0, 1, 1, 1}, dc[4] = {1, 1, 0, -1};             // dependants R, DR, D, DL
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const int nr = lr + dr[d], nc = lc + dc[d];
-                    if (nr < h && nc >= 0 && nc < w) s_dirty[nr * w + nc] = 1;
-                }
-            }
-        }
-        __syncthreads();
-    }
-
-    // write back, and tell the tiles that hold dependants of changed border blocks
-    for (int i = tid; i < h * w; i += 256) {
-        const int lr = i / w, lc = i - lr * w;
-        const int li = (lr + 1) * PIT + lc + 1;
-        const mv_t e = s_est[li];
-        const bool moved = e != s_seen[li];
-        if (a.first || moved) a.est[(size_t)(r0 + lr) * a.cols + c0 + lc] = e;
-        if (moved && (lr == h - 1 || lc == 0 || lc == w - 1)) {
-            const int dr[4] = {0, 1, 1, 1}, dc[4] = {1, 1, 0, -1};
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const int nr = lr + dr[d], nc = lc + dc[d];
-                if (nr < h && nc >= 0 && nc < w) continue;                         // inside this tile
-                const int rr = r0 + nr, cc = c0 + nc;
-                if (rr >= a.rows || cc < 0 || cc >= a.cols) continue;
-                a.tile_flags[(rr / a.tile_h) * a.tiles_x + cc / a.tile_w] = a.epoch + 1;
-            }
-        }
-    }
-}
-
-// Asynchronous solver (the exact finisher).  Every wave owns a private LDS queue.  It scans its share
-// of the grid for blocks that may still be inconsistent (after k_reg_tile: blocks with an input in the
-// halo of a tile that is still flagged; after k_reg_pass1: blocks pass 1 left stale), queues them, and whatever its own changes
+// Asynchronous solver.  Every wave owns a private LDS queue.  It scans its share of the grid for
+// blocks that pass 1 left stale (16 blocks at a time), queues them, and whatever its own changes
 // make stale it queues locally too and evaluates itself, round after round, without any grid-wide
 // step: fixed-point iteration tolerates any evaluation order.  A wave whose queue is empty and
 // which has scanned its share simply exits.  If a local queue is full the surplus goes to a
@@ -851,19 +686,8 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
         if (base < nblocks) {
             const uint32_t x = base + lane;
             bool mine = false;
-            if ((uint32_t)lane < SCAN && x < nblocks) {
-                const int r = (int)(x / a.cols), c = (int)(x % a.cols);
-                bool suspect;
-                if (a.tile_flags) {
-                    // after the tile launches: blocks with an input in the halo of a tile that is still flagged
-                    const int lr = r % a.tile_h, lc = c % a.tile_w;
-                    suspect = a.tile_flags[(r / a.tile_h) * a.tiles_x + c / a.tile_w] == a.epoch &&
-                              (lr == 0 || lc == 0 || lc == a.tile_w - 1 || c == a.cols - 1);
-                } else {
-                    suspect = block_is_stale(a, r, c);                  // directly after k_reg_pass1
-                }
-                if (suspect) mine = own_claim(a.own, x) == 0;
-            }
+            if ((uint32_t)lane < SCAN && x < nblocks && block_is_stale(a, (int)(x / a.cols), (int)(x % a.cols)))
+                mine = own_claim(a.own, x) == 0;
             enqueue(mine, x);
         } else if (head == tail) {
             break;
