@@ -32,6 +32,8 @@ WORKLOADS = {
     "cfg2": (1920, 1080, 48, 16, 3, "cfg2: 1080p synthetic pair, 16x16 blocks, +-16, 3 levels"),
     "cfg4": (3840, 2160, 72, 8, 4, "cfg4: 4K synthetic pair, 8x8 blocks, +-32, 4 levels"),
     "cfg1": (584, 388, 30, 16, 3, "cfg1: RubberWhale-sized synthetic pair, 16x16 blocks, +-7, 3 levels"),
+    "ref": (2336, 1552, 64, 32, 4, "reference literals (main_class.cpp:19-21): 584x388 frame up-sampled x4, 32x32 blocks, "
+                                   "search 64 (+-16), 4 levels"),
 }
 
 

@@ -60,6 +60,7 @@ struct bbme_ctx {
     uint8_t *raw[2] = {nullptr, nullptr};         // unpadded frames for bbme_set_frames_device staging
     bool frames_set = false;
     int solve_wgs = 1280;                         // most workgroups of k_reg_solve (4 independent waves each)
+    int xcd_remap = 1;                            // XCD-aware block order in k_search_fast; BBME_XCD_REMAP
     bool force_generic_search = false;            // BBME_GENERIC_SEARCH=1: use k_search_generic everywhere
     bool use_graph = true;
     hipGraphExec_t graph_exec = nullptr;
@@ -119,10 +120,13 @@ int launch_search_fast(bbme_ctx *c, int level)
     a.cols = L.width / L.block;
     a.pitch_dw = L.fast_pitch_dw;
     const int nblocks = (L.width / L.block) * (L.height / L.block);
+    a.nblocks = nblocks;
+    a.xcd_remap = c->xcd_remap;
+    const int grid = c->xcd_remap ? ((nblocks + 7) / 8) * 8 : nblocks;
     if (L.block == 16)
-        hipLaunchKernelGGL(k_search_fast<16>, dim3(nblocks), dim3(64), L.fast_lds_bytes, c->stream, a);
+        hipLaunchKernelGGL(k_search_fast<16>, dim3(grid), dim3(64), L.fast_lds_bytes, c->stream, a);
     else
-        hipLaunchKernelGGL(k_search_fast<8>, dim3(nblocks), dim3(64), L.fast_lds_bytes, c->stream, a);
+        hipLaunchKernelGGL(k_search_fast<8>, dim3(grid), dim3(64), L.fast_lds_bytes, c->stream, a);
     HIP_TRY(hipGetLastError());
     return BBME_OK;
 }
@@ -314,6 +318,7 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
     if (const char *e = getenv("BBME_SOLVE_WGS")) c->solve_wgs = std::max(1, std::min(8192, atoi(e)));
     if (const char *e = getenv("BBME_NO_GRAPH")) c->use_graph = atoi(e) == 0;
     if (const char *e = getenv("BBME_GENERIC_SEARCH")) c->force_generic_search = atoi(e) != 0;
+    if (const char *e = getenv("BBME_XCD_REMAP")) c->xcd_remap = atoi(e) != 0;
     c->lv.resize(nl);
     auto cleanup_fail = [&](int rc) { bbme_destroy(c); return rc; };
     hipError_t err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);

@@ -157,6 +157,8 @@ struct FastSearchArgs {
     mv_t *out;
     int cols;
     int pitch_dw;               // LDS window pitch in dwords (odd)
+    int nblocks;                // macroblocks of the level
+    int xcd_remap;              // 1 = XCD-aware block order
 };
 
 template <int B, int S>
@@ -233,7 +235,13 @@ __global__ __launch_bounds__(64) void k_search_fast(FastSearchArgs a)
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     constexpr int BW = B / 4;
     const int lane = threadIdx.x;
-    const int bc = blockIdx.x % a.cols, br = blockIdx.x / a.cols;
+    // Workgroups are dealt round-robin over the 8 XCDs, each with a private L2.  Give every XCD a
+    // contiguous eighth of the raster so that neighbouring macroblocks -- whose windows overlap by
+    // 80 % -- meet in the same L2.  Pure speed: any placement gives the same result.
+    const uint32_t chunk = (uint32_t)(a.nblocks + 7) / 8;
+    const uint32_t bid = a.xcd_remap ? (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3) : blockIdx.x;
+    if (bid >= (uint32_t)a.nblocks) return;
+    const int bc = (int)(bid % (uint32_t)a.cols), br = (int)(bid / (uint32_t)a.cols);
     const int i = br * B, j = bc * B;
 
     int u = 0, v = 0;                                       // copyMVs (:828-843)
