@@ -186,7 +186,7 @@ def main():
         # the binding ceiling is the issue rate of the SAD instructions; measure it on this device
         import ctypes as C
         from blockbasedmotionestimation_amd import _capi
-        rates = (C.c_double * 2)()
+        rates = (C.c_double * 4)()
         _capi.check(_capi.lib().bbme_probe_rates(local_rank, rates))
         qsad_peak = rates[0] * 64 * 16 / 1e3          # T abs-diff/s through v_qsad_pk_u16_u8 (what the kernel uses)
         sad_peak = rates[1] * 64 * 4 / 1e3            # T abs-diff/s through v_sad_u8

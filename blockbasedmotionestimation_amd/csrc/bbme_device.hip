@@ -732,17 +732,19 @@ int bbme_probe_rates(int device, double *gops)
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     const int iters = 4096, grid = 256 * 8;          // 8 workgroups of 4 waves per CU: 8 waves per SIMD
-    for (int which = 0; which < 2; ++which) {
+    for (int which = 0; which < 4; ++which) {
         for (int rep = 0; rep < 2; ++rep) {
             HIP_TRY(hipEventRecord(e0, 0));
             if (which == 0) hipLaunchKernelGGL(k_probe_rate<0>, dim3(grid), dim3(256), 0, 0, out, iters, 7u + rep);
-            else hipLaunchKernelGGL(k_probe_rate<1>, dim3(grid), dim3(256), 0, 0, out, iters, 7u + rep);
+            else if (which == 1) hipLaunchKernelGGL(k_probe_rate<1>, dim3(grid), dim3(256), 0, 0, out, iters, 7u + rep);
+            else if (which == 2) hipLaunchKernelGGL(k_probe_rate<2>, dim3(grid), dim3(256), 0, 0, out, iters, 7u + rep);
+            else hipLaunchKernelGGL(k_probe_rate<5>, dim3(grid), dim3(256), 0, 0, out, iters, 7u + rep);
             HIP_TRY(hipEventRecord(e1, 0));
             HIP_TRY(hipEventSynchronize(e1));
         }
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-        // wave-instructions per second over the whole chip, in units of 1e9
+        // wave-instructions per second over the whole chip, in units of 1e9 (mixed runs: QSADs only)
         gops[which] = (double)grid * 4 * iters * 8 / (ms * 1e-3) / 1e9;
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(out);

@@ -414,6 +414,32 @@ int bbme_subsample_div4(const float *flow_padded, int padded_width, int padded_h
     return BBME_OK;
 }
 
+int bbme_spiral_host(int search_size, int block_size, int16_t *dx, int16_t *dy, int capacity, int *count)
+{
+    if (!count) return bbme::fail(BBME_ERR_INVALID, "bbme_spiral_host: null count");
+    const bbme::SpiralTable t = bbme::build_spiral(search_size, block_size);
+    *count = (int)t.dx.size();
+    if (dx && dy)
+        for (int i = 0; i < *count && i < capacity; ++i) { dx[i] = t.dx[i]; dy[i] = t.dy[i]; }
+    return BBME_OK;
+}
+
+int bbme_search_plan_host(int range, int block_size, uint32_t *rounds, int rounds_capacity, int *nrounds,
+                          uint32_t *tasks, int *groups, int *pitch_dw)
+{
+    if (!nrounds || range < 0 || range > 63 || (block_size != 8 && block_size != 16))
+        return bbme::fail(BBME_ERR_INVALID, "bbme_search_plan_host: bad arguments");
+    const bbme::SearchPlan p = bbme::plan_search(range, block_size, 16);
+    *nrounds = (int)p.rounds.size();
+    if (groups) *groups = p.groups;
+    if (pitch_dw) *pitch_dw = p.pitch_dw;
+    for (int i = 0; i < *nrounds && i < rounds_capacity; ++i) {
+        if (rounds) rounds[i] = p.rounds[i];
+        if (tasks) memcpy(tasks + (size_t)i * 64, p.tasks.data() + (size_t)i * 64, 64 * sizeof(uint32_t));
+    }
+    return BBME_OK;
+}
+
 void bbme_free(void *p) { free(p); }
 
 }  // extern "C"

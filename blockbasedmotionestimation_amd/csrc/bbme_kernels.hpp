@@ -859,7 +859,7 @@ __global__ __launch_bounds__(256) void k_probe_rate(uint32_t *out, int iters, ui
         unsigned long long r = 0;
         for (int i = 0; i < 8; ++i) r ^= acc[i];
         if (r == 0x123456789abcdefull) out[0] = 1;
-    } else {
+    } else if constexpr (WHICH == 1) {
         uint32_t acc[8];
         for (int i = 0; i < 8; ++i) acc[i] = x + i;
         const uint32_t w = x * 2654435761u;
@@ -869,6 +869,25 @@ __global__ __launch_bounds__(256) void k_probe_rate(uint32_t *out, int iters, ui
         uint32_t r = 0;
         for (int i = 0; i < 8; ++i) r ^= acc[i];
         if (r == 0x12345678u) out[0] = 1;
+    } else {
+        // mixed: per iteration 8 QSADs and 8*RATIO SADs, independent chains (do the two overlap?)
+        constexpr int RATIO = WHICH - 1;                         // WHICH = 2 -> 1:1, 5 -> 1:4
+        unsigned long long qa[8];
+        uint32_t sa[8];
+        for (int i = 0; i < 8; ++i) { qa[i] = x + i; sa[i] = x * 3 + i; }
+        const unsigned long long pair = ((unsigned long long)(x * 2654435761u) << 32) | (x * 40503u);
+        const uint32_t w = x * 2246822519u;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                qa[i] = __builtin_amdgcn_qsad_pk_u16_u8(pair, x + i, qa[i]);
+#pragma unroll
+                for (int k = 0; k < RATIO; ++k) sa[(i + k) & 7] = __builtin_amdgcn_sad_u8(w, x + i + k, sa[(i + k) & 7]);
+            }
+        }
+        unsigned long long r = 0;
+        for (int i = 0; i < 8; ++i) r ^= qa[i] ^ sa[i];
+        if (r == 0x123456789abcdefull) out[0] = 1;
     }
 }
 

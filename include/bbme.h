@@ -79,6 +79,14 @@ int bbme_subsample_div4(const float *flow_padded, int padded_width, int padded_h
                         int pad_x, int pad_y, float *out, int out_width, int out_height);
 void bbme_free(void *p);
 
+/* Host tables of the search kernels, exposed for tests.  bbme_spiral_host: visiting order of
+ * find_min_block_spiral (motion_framework.cpp:326-411), rank -> (dx, dy).  bbme_search_plan_host: the
+ * work split of k_search_fast -- strip height per round and 64 tasks (g | dy0 << 8, 0xffffffff = idle
+ * lane) per round; together the tasks must cover every (column group, candidate row) exactly once. */
+int bbme_spiral_host(int search_size, int block_size, int16_t *dx, int16_t *dy, int capacity, int *count);
+int bbme_search_plan_host(int range, int block_size, uint32_t *rounds, int rounds_capacity, int *nrounds,
+                          uint32_t *tasks /* rounds_capacity * 64 */, int *groups, int *pitch_dw);
+
 /* ---- context: one per GPU stream (replaces an MF object) ---------------------------- */
 
 /* Allocates every device buffer for a (width x height) frame pair: padded planes of
@@ -158,7 +166,8 @@ int bbme_get_timings(bbme_ctx *ctx, float *total_ms, float *search_ms, float *re
 
 /* Measures the chip-wide issue rate of v_qsad_pk_u16_u8 (gops[0]) and v_sad_u8 (gops[1]) in 1e9
  * wave-instructions per second (8 waves per SIMD, 8 independent chains per lane): the VALU
- * ceilings bench.py prices the search kernel against. */
+ * ceilings bench.py prices the search kernel against.  gops[2] / gops[3]: QSAD rate when every QSAD
+ * is interleaved with one / four independent v_sad_u8 (do the two instructions overlap?). */
 int bbme_probe_rates(int device, double *gops);
 
 /* Profiling aid: launches a kernel that reads `mbytes` MiB exactly once with one aligned dword per

@@ -32,6 +32,12 @@ CASES = [
     (256, 128, [17, 21], [16, 16], 1009, 3),                    # odd shift (search-block odd), tiny ranges
     (128, 128, [16], [16], 1010, 0),                            # search_size == block_size: centre only
     (256, 192, [12, 12], [4, 4], 1011, 5),                      # B=4
+    (512, 512, [80, 80], [64, 64], 1012, 10),                   # B=64 (generic search, 64-lane regulariser groups)
+    (640, 512, [20, 20, 20, 24, 24], [4, 4, 4, 8, 8], 1013, 30),  # five levels, large coarse-to-fine motion
+    (256, 128, [8, 12], [16, 16], 1014, 2),                     # search_size < block_size: centre candidate only
+    (250, 130, [30], [16], 1015, 5),                            # odd-looking size, padded both ways (256 x 144)
+    (1024, 64, [48, 48], [16, 16], 1016, 12),                   # two block rows at the coarse level, very wide
+    (64, 1024, [48, 48], [16, 16], 1017, 12),                   # two block columns, very tall
 ]
 
 

@@ -166,3 +166,55 @@ def test_cli_builds_and_fails_loudly_without_gpu(bbme, tmp_path):
         r = subprocess.run([_build.CLI, str(tmp_path / "a.pgm"), str(tmp_path / "b.pgm"), "--levels", "1", "--block", "16",
                             "--search", "30"], capture_output=True, text=True)
         assert r.returncode == 1 and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.parametrize("search,block", [(30, 16), (48, 16), (80, 16), (72, 8), (64, 32), (16, 16), (17, 16), (21, 16),
+                                          (10, 16), (142, 16), (33, 8)])
+def test_spiral_table_equals_reference_loop_walk(bbme, oracle, search, block):
+    """The product's rank -> (dx, dy) table (built in libbbme.so) against the oracle's literal walk of
+    motion_framework.cpp:326-411."""
+    from blockbasedmotionestimation_amd import _capi
+    n = C.c_int()
+    _capi.check(_capi.lib().bbme_spiral_host(search, block, None, None, 0, C.byref(n)))
+    dx = np.zeros(n.value, np.int16)
+    dy = np.zeros(n.value, np.int16)
+    _capi.check(_capi.lib().bbme_spiral_host(search, block, dx.ctypes.data, dy.ctypes.data, n.value, C.byref(n)))
+    odx, ody = oracle.spiral_walk(search - block)
+    assert n.value == len(odx)
+    assert np.array_equal(dx, odx) and np.array_equal(dy, ody)
+
+
+@pytest.mark.parametrize("block", [8, 16])
+@pytest.mark.parametrize("rng", [0, 1, 2, 3, 7, 8, 15, 16, 17, 31, 32, 33, 45, 63])
+def test_search_plan_covers_every_candidate_once(bbme, rng, block):
+    """k_search_fast's work split: every (column group, candidate row) in exactly one strip, strips of a
+    round all of the round's height, at most 64 per round, rounds full except possibly the last."""
+    from blockbasedmotionestimation_amd import _capi
+    cap = 256
+    rounds = np.zeros(cap, np.uint32)
+    tasks = np.zeros((cap, 64), np.uint32)
+    nr, groups, pitch = C.c_int(), C.c_int(), C.c_int()
+    _capi.check(_capi.lib().bbme_search_plan_host(rng, block, rounds.ctypes.data, cap, C.byref(nr), tasks.ctypes.data,
+                                                  C.byref(groups), C.byref(pitch)))
+    n = 2 * rng + 1
+    assert groups.value == (n + 3) // 4 and 1 <= nr.value <= cap
+    assert pitch.value % 2 == 1 and pitch.value >= groups.value + block // 4
+    covered = np.zeros((groups.value, n), np.int32)
+    for r in range(nr.value):
+        s = int(rounds[r])
+        assert s in (16, 8, 4, 2, 1)
+        busy = 0
+        for t in tasks[r]:
+            if t == 0xFFFFFFFF:
+                continue
+            busy += 1
+            g, dy0 = int(t & 0xFF), int((t >> 8) & 0xFF)
+            assert g < groups.value and dy0 + s <= n
+            covered[g, dy0:dy0 + s] += 1
+        assert 1 <= busy <= 64
+        if r < nr.value - 1:
+            assert busy == 64 or s == 1
+    assert np.all(covered == 1)
+    # a round costs its strip height; the plan should stay close to the ideal n * groups / 64
+    cost = int(sum(int(rounds[r]) for r in range(nr.value)))
+    assert cost <= -(-n * groups.value // 64) + 2
