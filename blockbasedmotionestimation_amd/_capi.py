@@ -84,6 +84,7 @@ SIGNATURES = {
     "bbme_set_profiling": (C.c_int, [_ctx, C.c_int]),
     "bbme_get_timings": (C.c_int, [_ctx] + [_P(C.c_float)] * 5),
     "bbme_probe_rates": (C.c_int, [C.c_int, _P(C.c_double)]),
+    "bbme_probe_latency": (C.c_int, [C.c_int, _P(C.c_ulonglong)]),
     "bbme_calibrate_read": (C.c_int, [C.c_int, C.c_uint, C.c_int]),
     "bbme_selftest_isa": (C.c_int, [C.c_int, _P(C.c_int)]),
 }

@@ -751,6 +751,27 @@ int bbme_probe_rates(int device, double *gops)
     return BBME_OK;
 }
 
+int bbme_probe_latency(int device, unsigned long long *out9)
+{
+    if (!out9) return bbme::fail(BBME_ERR_INVALID, "null output");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return bbme::fail(BBME_ERR_HIP, "no HIP device %d", device);
+    HIP_TRY(hipSetDevice(device));
+    const uint32_t nwords = 1u << 18;                       // 1 MiB: beyond L1, inside an L2
+    std::vector<uint32_t> host(nwords);
+    uint32_t x = 12345;
+    for (uint32_t i = 0; i < nwords; ++i) { x = x * 1664525u + 1013904223u; host[i] = x; }
+    uint32_t *buf = nullptr; unsigned long long *out = nullptr;
+    HIP_TRY(hipMalloc(&buf, nwords * 4)); HIP_TRY(hipMalloc(&out, 9 * 8));
+    HIP_TRY(hipMemcpy(buf, host.data(), nwords * 4, hipMemcpyHostToDevice));
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(k_probe_latency, dim3(1), dim3(64), 0, 0, buf, nwords, out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out9, out, 9 * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(buf); (void)hipFree(out);
+    return BBME_OK;
+}
+
 int bbme_calibrate_read(int device, unsigned mbytes, int repeats)
 {
     int ndev = 0;

@@ -891,6 +891,40 @@ __global__ __launch_bounds__(256) void k_probe_rate(uint32_t *out, int iters, ui
     }
 }
 
+// dependent-chain latencies of the memory operations the solver round is made of (one wave, one lane
+// active, otherwise idle chip): cycles (s_memtime) and 10 ns ticks (s_memrealtime) per operation
+__global__ void k_probe_latency(uint32_t *buf, uint32_t nwords, unsigned long long *out)
+{
+    if (threadIdx.x != 0) return;
+    const int N = 256;
+    uint32_t idx = 1;
+    unsigned long long c0, c1, r0, r1;
+    // (0) plain load chain (pointer chasing over a buffer larger than L1, smaller than L2)
+    c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < N; ++i) idx = buf[idx % nwords];
+    c1 = __builtin_amdgcn_s_memtime(); r1 = __builtin_amdgcn_s_memrealtime();
+    out[0] = (c1 - c0) / N; out[1] = (r1 - r0);
+    // (1) agent-scope (sc1) load chain
+    c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < N; ++i) idx = __hip_atomic_load(&buf[idx % nwords], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    c1 = __builtin_amdgcn_s_memtime(); r1 = __builtin_amdgcn_s_memrealtime();
+    out[2] = (c1 - c0) / N; out[3] = (r1 - r0);
+    // (2) returning atomic chain
+    c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < N; ++i) idx = atomicAdd(&buf[(idx * 2654435761u) % nwords], 0u) + i;
+    c1 = __builtin_amdgcn_s_memtime(); r1 = __builtin_amdgcn_s_memrealtime();
+    out[4] = (c1 - c0) / N; out[5] = (r1 - r0);
+    // (3) agent-scope store + drain
+    c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < N; ++i) {
+        __hip_atomic_store(&buf[(idx + 64 * i) % nwords], idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    c1 = __builtin_amdgcn_s_memtime(); r1 = __builtin_amdgcn_s_memrealtime();
+    out[6] = (c1 - c0) / N; out[7] = (r1 - r0);
+    out[8] = idx;
+}
+
 // unaligned global loads: dword / dwordx2 / dwordx4 at arbitrary byte addresses
 struct __attribute__((packed, aligned(1))) ua_u32 { uint32_t v; };
 struct __attribute__((packed, aligned(1))) ua_u32x2 { uint32_t v[2]; };

@@ -170,6 +170,11 @@ int bbme_get_timings(bbme_ctx *ctx, float *total_ms, float *search_ms, float *re
  * is interleaved with one / four independent v_sad_u8 (do the two instructions overlap?). */
 int bbme_probe_rates(int device, double *gops);
 
+/* Dependent-chain latency of the memory operations a solver round is made of, one lane on an idle
+ * chip: out[2k] = shader cycles per operation, out[2k+1] = 10 ns ticks for 256 operations, for
+ * k = 0 plain load, 1 agent-scope load, 2 returning atomic, 3 agent-scope store + drain. */
+int bbme_probe_latency(int device, unsigned long long *out9);
+
 /* Profiling aid: launches a kernel that reads `mbytes` MiB exactly once with one aligned dword per
  * lane (the access shape of the search kernel's window staging), `repeats` times, so that the
  * FETCH_SIZE counter can be calibrated against a known byte count in the same rocprofv3 run. */
