@@ -59,6 +59,27 @@ def pmc_traffic(levels):
         return None
 
 
+def epe_on_ground_truth(bbme, device):
+    """Average end-point error of the reference's own pipeline and literals (4x bilinear up-sampling, 4
+    levels, block 32, search 64, every 4th pixel / 4; main_class.cpp:19-21,32-33,58-70) against Middlebury
+    ground truth.  The Middlebury frames are not in the reference (only its GT .flo files are), so the pair
+    is a texture warped by the Venus ground truth, which makes that file the true flow of the pair."""
+    gt_path = os.path.join(ROOT, "tests", "golden", "gt_Venus_flow10.flo")
+    if not os.path.exists(gt_path):
+        return None
+    gt = bbme.Flow().ReadFlowFile(gt_path)
+    h, w = gt.shape[:2]
+    f1, f2 = bbme.warp_pair_from_flow(gt)
+    u1, u2 = bbme.resize_x4(f1), bbme.resize_x4(f2)
+    mf = bbme.MF(u1, u2, [64] * 4, [32] * 4, 4, device=device)
+    flow = mf.calcMotionBlockMatching()
+    sub = bbme.subsample_div4(flow, mf.padding_x, mf.padding_y, w, h)
+    mf.close()
+    return {"value": round(bbme.Flow().CalculateMSE(gt, sub), 6), "unit": "px",
+            "data": "texture warped by Middlebury Venus flow10.flo (420x380); reference pipeline: x4 bilinear, "
+                    "4 levels, 32x32 blocks, search 64"}
+
+
 def cpu_baseline(f1, f2, search, block, levels, expect_flow):
     """The oracle (CPU restatement, 1 thread, rebuilt here with -march=native) timed on the same pair."""
     src = os.path.join(ROOT, "oracle", "bbme_oracle.c")
@@ -221,6 +242,7 @@ def main():
                                                      "x 16 abs-diff per lane (v_sad_u8: %.1f T/s)" % sad_peak}},
             "device_ms": {k: round(val, 4) for k, val in prof.items()},
         }
+        out["epe_vs_middlebury_gt"] = epe_on_ground_truth(bbme, local_rank)
         if not args.no_cpu_baseline:
             dt, parity = cpu_baseline(f1, f2, search, block, levels, result_flow)
             out["cpu_baseline"] = {"value": round(blocks[0] / dt / 1e6, 5), "unit": "Mblocks/s", "cores": 1,

@@ -57,7 +57,6 @@ struct bbme_ctx {
     uint32_t *list[2] = {nullptr, nullptr};
     uint32_t *own = nullptr;                      // ownership counters of the solver, 16 bits per block
     uint32_t *counters = nullptr;                 // 8 words
-    uint8_t *raw[2] = {nullptr, nullptr};         // unpadded frames for bbme_set_frames_device staging
     bool frames_set = false;
     int solve_wgs = 1280;                         // most workgroups of k_reg_solve (4 independent waves each)
     int xcd_remap = 1;                            // XCD-aware block order in k_search_fast; BBME_XCD_REMAP
@@ -230,9 +229,8 @@ int launch_expand(bbme_ctx *c)
 }
 
 // The level loop of MF::calcMotionBlockMatching (:115-206)
-int enqueue_pyramid(bbme_ctx *c, hipEvent_t *ev /* optional: 2 + 3*levels + ... */)
+int enqueue_pyramid(bbme_ctx *c)
 {
-    (void)ev;
     for (int l = (int)c->lv.size() - 1; l >= 0; --l) {
         if (int rc = launch_search(c, l)) return rc;
         for (int b = c->lv[l].block; b > 1; b >>= 1)              // while (block_size > 1) :141
@@ -365,14 +363,11 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
     }
     const size_t bit_words = (max_blocks + 1) / 2 + 4;
     const size_t flow_bytes = (size_t)g.padded_width * g.padded_height * 2 * sizeof(float);
-    const size_t raw_bytes = (size_t)width * height + 64;
     if ((err = hipMalloc(&c->flow, flow_bytes)) != hipSuccess ||
         (err = hipMalloc(&c->list[0], max_blocks * 4)) != hipSuccess ||
         (err = hipMalloc(&c->list[1], max_blocks * 4)) != hipSuccess ||
         (err = hipMalloc(&c->own, bit_words * 4)) != hipSuccess ||
         (err = hipMalloc(&c->counters, 64)) != hipSuccess ||
-        (err = hipMalloc(&c->raw[0], raw_bytes)) != hipSuccess ||
-        (err = hipMalloc(&c->raw[1], raw_bytes)) != hipSuccess ||
         (err = hipMemset(c->own, 0, bit_words * 4)) != hipSuccess ||
         (err = hipMemset(c->counters, 0, 64)) != hipSuccess ||
         (err = hipMemset(c->flow, 0, flow_bytes)) != hipSuccess)
@@ -398,7 +393,6 @@ int bbme_destroy(bbme_ctx *c)
     (void)hipFree(c->list[0]); (void)hipFree(c->list[1]);
     (void)hipFree(c->own);
     (void)hipFree(c->counters);
-    (void)hipFree(c->raw[0]); (void)hipFree(c->raw[1]);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return BBME_OK;
@@ -530,12 +524,12 @@ int bbme_estimate(bbme_ctx *c)
     if (!c->frames_set) return bbme::fail(BBME_ERR_STATE, "bbme_estimate: no frames set");
     HIP_TRY(hipSetDevice(c->device));
     if (c->profiling) return profiled_pyramid(c);
-    if (!c->use_graph) return enqueue_pyramid(c, nullptr);
+    if (!c->use_graph) return enqueue_pyramid(c);
     if (!c->graph_exec) {
         // the launch sequence is fixed (no host decisions inside), so capture it once
         hipGraph_t graph = nullptr;
         HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        int rc = enqueue_pyramid(c, nullptr);
+        int rc = enqueue_pyramid(c);
         hipError_t e = hipStreamEndCapture(c->stream, &graph);
         if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
         if (e != hipSuccess) return bbme::fail(BBME_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));

@@ -45,3 +45,23 @@ def synth_pair(width, height, seed, max_motion=24, tiles=4, noise=2):
         frame2 = frame2 + rng2.integers(-noise, noise + 1, size=frame2.shape)
     frame2 = np.clip(frame2, 0, 255).astype(np.uint8)
     return frame1, frame2, motion
+
+
+def warp_pair_from_flow(flow, seed=4711):
+    """A frame pair whose true flow is `flow` ((H, W, 2) float32, Middlebury convention, unknown pixels
+    > 1e9): frame2 is a seeded texture, frame1(x) = frame2(x + flow(x)) by bilinear sampling.  Stands in
+    for the Middlebury frames, which the reference does not ship (only its ground-truth .flo files)."""
+    h, w = flow.shape[:2]
+    m = 32
+    tex, _, _ = synth_pair(w + 2 * m, h + 2 * m, seed, max_motion=0, noise=0)
+    frame2 = tex[m:m + h, m:m + w].copy()
+    f = np.where(np.abs(flow) > 1e9, 0.0, flow).astype(np.float64)
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    sx = np.clip(xs + f[..., 0] + m, 0, w + 2 * m - 2)
+    sy = np.clip(ys + f[..., 1] + m, 0, h + 2 * m - 2)
+    x0, y0 = np.floor(sx).astype(int), np.floor(sy).astype(int)
+    fx, fy = sx - x0, sy - y0
+    t = tex.astype(np.float64)
+    frame1 = ((1 - fy) * ((1 - fx) * t[y0, x0] + fx * t[y0, x0 + 1]) +
+              fy * ((1 - fx) * t[y0 + 1, x0] + fx * t[y0 + 1, x0 + 1]))
+    return np.clip(np.rint(frame1), 0, 255).astype(np.uint8), frame2

@@ -205,17 +205,7 @@ def test_epe_against_middlebury_ground_truth_warped_pair(bbme, oracle):
     from conftest import GOLDEN
     gt = bbme.Flow().ReadFlowFile(os.path.join(GOLDEN, "gt_Venus_flow10.flo"))
     h, w = gt.shape[:2]
-    tex, _, _ = bbme.synth_pair(w + 64, h + 64, 4711, max_motion=0, noise=0)
-    frame2 = tex[32:32 + h, 32:32 + w]
-    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
-    sx = np.clip(xs + gt[..., 0] + 32, 0, w + 62)
-    sy = np.clip(ys + gt[..., 1] + 32, 0, h + 62)
-    x0, y0 = np.floor(sx).astype(int), np.floor(sy).astype(int)
-    fx, fy = sx - x0, sy - y0
-    t = tex.astype(np.float64)
-    frame1 = ((1 - fy) * ((1 - fx) * t[y0, x0] + fx * t[y0, x0 + 1]) +
-              fy * ((1 - fx) * t[y0 + 1, x0] + fx * t[y0 + 1, x0 + 1]))
-    frame1 = np.clip(np.rint(frame1), 0, 255).astype(np.uint8)
+    frame1, frame2 = bbme.warp_pair_from_flow(gt)
     search, block = [64] * 4, [32] * 4
     u1, u2 = bbme.resize_x4(frame1), bbme.resize_x4(frame2)
     assert np.array_equal(u1, oracle.resize_linear_x4(frame1))
