@@ -124,6 +124,8 @@ int launch_search_fast(bbme_ctx *c, int level)
     const int grid = c->xcd_remap ? ((nblocks + 7) / 8) * 8 : nblocks;
     if (L.block == 16)
         hipLaunchKernelGGL(k_search_fast<16>, dim3(grid), dim3(64), L.fast_lds_bytes, c->stream, a);
+    else if (L.block == 32)
+        hipLaunchKernelGGL(k_search_fast<32>, dim3(grid), dim3(64), L.fast_lds_bytes, c->stream, a);
     else
         hipLaunchKernelGGL(k_search_fast<8>, dim3(grid), dim3(64), L.fast_lds_bytes, c->stream, a);
     HIP_TRY(hipGetLastError());
@@ -344,14 +346,15 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
             (err = hipMemset(L.img1, 0, plane)) != hipSuccess || (err = hipMemset(L.img2, 0, plane)) != hipSuccess ||
             (err = hipMemcpy(L.spiral, packed.data(), packed.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
             return cleanup_fail(bbme::fail(BBME_ERR_HIP, "allocating level %d: %s", l, hipGetErrorString(err)));
-        if (L.block == 8 || L.block == 16) {
+        if (L.block == 8 || L.block == 16 || (L.block == 32 && L.range <= 45)) {
             // the strip kernel reads rank rows dy0 .. dy0+S-1 as 4 x u16 per column group
-            SearchPlan plan = plan_search(L.range, L.block, 16);
+            SearchPlan plan = plan_search(L.range, L.block, L.block == 32 ? 8 : 16);
             L.fast = true;
             L.rank_pitch = sp.rank_pitch;
             L.nrounds = (int)plan.rounds.size();
             L.fast_pitch_dw = plan.pitch_dw;
-            L.fast_lds_bytes = (size_t)(L.block + 2 * L.range) * plan.pitch_dw * 4;
+            L.fast_lds_bytes = (size_t)(L.block + 2 * L.range) * plan.pitch_dw * 4 +
+                               (L.block == 32 ? (size_t)L.block * L.block : 0);   // B = 32: the current block too
             if ((err = hipMalloc(&L.rank_of, sp.rank_of.size() * 2 + 64)) != hipSuccess ||
                 (err = hipMalloc(&L.tasks, plan.tasks.size() * 4)) != hipSuccess ||
                 (err = hipMalloc(&L.rounds, plan.rounds.size() * 4)) != hipSuccess ||

@@ -427,9 +427,9 @@ int bbme_spiral_host(int search_size, int block_size, int16_t *dx, int16_t *dy, 
 int bbme_search_plan_host(int range, int block_size, uint32_t *rounds, int rounds_capacity, int *nrounds,
                           uint32_t *tasks, int *groups, int *pitch_dw)
 {
-    if (!nrounds || range < 0 || range > 63 || (block_size != 8 && block_size != 16))
+    if (!nrounds || range < 0 || range > 63 || (block_size != 8 && block_size != 16 && block_size != 32))
         return bbme::fail(BBME_ERR_INVALID, "bbme_search_plan_host: bad arguments");
-    const bbme::SearchPlan p = bbme::plan_search(range, block_size, 16);
+    const bbme::SearchPlan p = bbme::plan_search(range, block_size, block_size == 32 ? 8 : 16);
     *nrounds = (int)p.rounds.size();
     if (groups) *groups = p.groups;
     if (pitch_dw) *pitch_dw = p.pitch_dw;

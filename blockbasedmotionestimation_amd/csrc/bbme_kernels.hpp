@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64) void k_search_generic(SearchArgs a)
 }
 
 // =======================================================================================
-// K1 (fast form, B = 8 or 16): same function, same results, built around v_qsad_pk_u16_u8.
+// K1 (fast form, B = 8, 16 or 32): same function, same results, built around v_qsad_pk_u16_u8.
 //
 // One wavefront per macroblock.  The (B+2R)^2 window of image2 is staged in LDS re-aligned so
 // that candidate column dx = -R starts on a dword; the BxB block of image1 sits in SGPRs (its
@@ -161,18 +161,41 @@ struct FastSearchArgs {
     int xcd_remap;              // 1 = XCD-aware block order
 };
 
+// Current block operand: B <= 16 keeps the block in SGPRs (cur), B = 32 reads it from LDS with
+// wave-uniform addresses (cur_lds, B*B/4 dwords).
+template <int B> struct CurBlock {
+    uint32_t sg[B <= 16 ? B : 1][B <= 16 ? B / 4 : 1];
+    const uint32_t *lds;
+    __device__ __forceinline__ uint32_t at(int row, int q) const
+    {
+        if constexpr (B <= 16) return sg[row][q];
+        else return lds[row * (B / 4) + q];
+    }
+};
+
 template <int B, int S>
-__device__ __forceinline__ uint32_t search_strip(const uint32_t *win, int P, const uint32_t (&cur)[B][B / 4],
+__device__ __forceinline__ uint32_t search_strip(const uint32_t *win, int P, const CurBlock<B> &cur,
                                                  uint32_t task, const FastSearchArgs &a, uint32_t best,
                                                  bool border, int xlo, int xhi, int ylo, int yhi)
 {
     constexpr int BW = B / 4;
+    // packed u16 sums hold at most 256 pixels (255 * 256 < 2^16): B = 32 flushes them into 32-bit sums
+    // after every 8 block rows
+    constexpr bool WIDE = B > 16;
+    constexpr int FLUSH = 256 / B;
     const bool idle = task == 0xffffffffu;
     const int g = idle ? 0 : (int)(task & 0xffu);
     const int dy0 = idle ? 0 : (int)((task >> 8) & 0xffu);
     unsigned long long acc[S];
+    uint32_t acc32[WIDE ? S : 1][4];
 #pragma unroll
     for (int d = 0; d < S; ++d) acc[d] = 0;
+    if constexpr (WIDE) {
+#pragma unroll
+        for (int d = 0; d < S; ++d)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc32[d][c] = 0;
+    }
     // One window row ahead is kept in flight.  The QSAD chains are pure, so the optimiser would
     // sink all of them below all of the LDS reads (150+ live VGPRs, occupancy gone); the empty asm
     // statements pin the order: reads of row yy+1, then the QSADs of row yy, row after row.
@@ -196,10 +219,21 @@ __device__ __forceinline__ uint32_t search_strip(const uint32_t *win, int P, con
         for (int d = 0; d < S; ++d) {
             const int brow = yy - d;                       // row of the current block this window row meets
             if (brow < 0 || brow >= B) continue;
+            // B = 32: re-read the block row from LDS here (uniform address, cheap next to 24-cycle QSADs)
+            // instead of letting the compiler keep all 256 dwords of the block in VGPRs
+            if constexpr (WIDE) asm volatile("" ::: "memory");
 #pragma unroll
             for (int q = 0; q < BW; ++q) {
                 const unsigned long long pair = ((unsigned long long)w[q + 1] << 32) | w[q];
-                acc[d] = __builtin_amdgcn_qsad_pk_u16_u8(pair, cur[brow][q], acc[d]);
+                acc[d] = __builtin_amdgcn_qsad_pk_u16_u8(pair, cur.at(brow, q), acc[d]);
+            }
+            if constexpr (WIDE) {
+                if ((brow % FLUSH) == FLUSH - 1) {
+                    const uint32_t lo = (uint32_t)acc[d], hi = (uint32_t)(acc[d] >> 32);
+                    acc32[d][0] += lo & 0xffffu; acc32[d][1] += lo >> 16;
+                    acc32[d][2] += hi & 0xffffu; acc32[d][3] += hi >> 16;
+                    acc[d] = 0;
+                }
             }
             asm volatile("" : "+v"(acc[d]));
         }
@@ -214,17 +248,29 @@ __device__ __forceinline__ uint32_t search_strip(const uint32_t *win, int P, con
     const uint16_t *rk = a.rank_of + (size_t)dy0 * a.rank_pitch + 4 * g;
 #pragma unroll
     for (int d = 0; d < S; ++d) {
-        unsigned long long v = acc[d] | colmask;
-        if (border && (dy0 + d < ylo || dy0 + d > yhi)) v = ~0ull;
         const uint2 r4 = *reinterpret_cast<const uint2 *>(rk);
         rk += a.rank_pitch;
-        const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-        // key = (sad << 16) | rank, assembled bytewise: v_perm_b32(S0 = sums, S1 = ranks)
-        const uint32_t k0 = __builtin_amdgcn_perm(lo, r4.x, 0x05040100u);
-        const uint32_t k1 = __builtin_amdgcn_perm(lo, r4.x, 0x07060302u);
-        const uint32_t k2 = __builtin_amdgcn_perm(hi, r4.y, 0x05040100u);
-        const uint32_t k3 = __builtin_amdgcn_perm(hi, r4.y, 0x07060302u);
-        best = min(best, min(min(k0, k1), min(k2, k3)));
+        const bool row_bad = border && (dy0 + d < ylo || dy0 + d > yhi);
+        if constexpr (!WIDE) {
+            unsigned long long v = acc[d] | colmask;
+            if (row_bad) v = ~0ull;
+            const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+            // key = (sad << 16) | rank, assembled bytewise: v_perm_b32(S0 = sums, S1 = ranks)
+            const uint32_t k0 = __builtin_amdgcn_perm(lo, r4.x, 0x05040100u);
+            const uint32_t k1 = __builtin_amdgcn_perm(lo, r4.x, 0x07060302u);
+            const uint32_t k2 = __builtin_amdgcn_perm(hi, r4.y, 0x05040100u);
+            const uint32_t k3 = __builtin_amdgcn_perm(hi, r4.y, 0x07060302u);
+            best = min(best, min(min(k0, k1), min(k2, k3)));
+        } else {
+            // key = (sad << 13) | rank: sad < 2^18 (255 * 32 * 32), rank < 2^13 (range <= 45)
+            const uint32_t rank[4] = {r4.x & 0xffffu, r4.x >> 16, r4.y & 0xffffu, r4.y >> 16};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bool bad = row_bad || ((colmask >> (16 * c)) & 1ull);
+                const uint32_t key = bad ? 0xffffffffu : ((acc32[d][c] << 13) | rank[c]);
+                best = min(best, key);
+            }
+        }
     }
     return best;
 }
@@ -282,13 +328,22 @@ __global__ __launch_bounds__(64) void k_search_fast(FastSearchArgs a)
             }
         }
     }
-    // the current block: wave-uniform addresses -> scalar loads, lives in SGPRs
-    uint32_t cur[B][BW];
+    // the current block: B <= 16: wave-uniform addresses -> scalar loads, lives in SGPRs;
+    // B = 32: 256 dwords, staged in LDS behind the window and read back with uniform addresses
+    CurBlock<B> cur;
+    cur.lds = smem + wrows * P;
+    if constexpr (B <= 16) {
 #pragma unroll
-    for (int r = 0; r < B; ++r) {
-        const uint32_t *c1 = reinterpret_cast<const uint32_t *>(a.image1 + (size_t)(i + r) * a.width + j);
+        for (int r = 0; r < B; ++r) {
+            const uint32_t *c1 = reinterpret_cast<const uint32_t *>(a.image1 + (size_t)(i + r) * a.width + j);
 #pragma unroll
-        for (int q = 0; q < BW; ++q) cur[r][q] = __builtin_amdgcn_readfirstlane(c1[q]);
+            for (int q = 0; q < BW; ++q) cur.sg[r][q] = __builtin_amdgcn_readfirstlane(c1[q]);
+        }
+    } else {
+        for (int idx = lane; idx < B * BW; idx += 64) {
+            const int r = idx / BW, q = idx - r * BW;
+            smem[wrows * P + idx] = *reinterpret_cast<const uint32_t *>(a.image1 + (size_t)(i + r) * a.width + j + 4 * q);
+        }
     }
     __syncthreads();
 
@@ -302,7 +357,7 @@ __global__ __launch_bounds__(64) void k_search_fast(FastSearchArgs a)
         const uint32_t S = a.rounds[rd];
         const uint32_t task = a.tasks[rd * 64 + lane];
         switch (S) {
-        case 16: best = search_strip<B, 16>(smem, P, cur, task, a, best, border, xlo, xhi, ylo, yhi); break;
+        case 16: if constexpr (B <= 16) { best = search_strip<B, 16>(smem, P, cur, task, a, best, border, xlo, xhi, ylo, yhi); } break;
         case 8:  best = search_strip<B, 8>(smem, P, cur, task, a, best, border, xlo, xhi, ylo, yhi); break;
         case 4:  best = search_strip<B, 4>(smem, P, cur, task, a, best, border, xlo, xhi, ylo, yhi); break;
         case 2:  best = search_strip<B, 2>(smem, P, cur, task, a, best, border, xlo, xhi, ylo, yhi); break;
@@ -312,7 +367,7 @@ __global__ __launch_bounds__(64) void k_search_fast(FastSearchArgs a)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o));
     if (lane == 0) {
-        const uint32_t sp = a.spiral[best & 0xffffu];
+        const uint32_t sp = a.spiral[best & (B > 16 ? 0x1fffu : 0xffffu)];
         *dst = mv_pack(u + (int)(int16_t)(sp & 0xffffu), v + (int)(int16_t)(sp >> 16));   // :238-239
     }
 }

@@ -184,7 +184,7 @@ def test_spiral_table_equals_reference_loop_walk(bbme, oracle, search, block):
     assert np.array_equal(dx, odx) and np.array_equal(dy, ody)
 
 
-@pytest.mark.parametrize("block", [8, 16])
+@pytest.mark.parametrize("block", [8, 16, 32])
 @pytest.mark.parametrize("rng", [0, 1, 2, 3, 7, 8, 15, 16, 17, 31, 32, 33, 45, 63])
 def test_search_plan_covers_every_candidate_once(bbme, rng, block):
     """k_search_fast's work split: every (column group, candidate row) in exactly one strip, strips of a
@@ -202,7 +202,7 @@ def test_search_plan_covers_every_candidate_once(bbme, rng, block):
     covered = np.zeros((groups.value, n), np.int32)
     for r in range(nr.value):
         s = int(rounds[r])
-        assert s in (16, 8, 4, 2, 1)
+        assert s in ((8, 4, 2, 1) if block == 32 else (16, 8, 4, 2, 1))
         busy = 0
         for t in tasks[r]:
             if t == 0xFFFFFFFF:
