@@ -431,7 +431,7 @@ __device__ __forceinline__ mv_t load_est(const mv_t *p)
 // that exist in the grid.  Every image row of every candidate is loaded in ONE memory trip: loads are
 // unconditional -- out-of-image candidates read a clamped, harmless address and are masked afterwards
 // -- because a load inside a divergent `if` costs its own round trip.
-template <int BS>
+template <int BS, bool DEDUP = false>
 __device__ __forceinline__ mv_t score_block(const RegArgs &a, const mv_t (&cand)[9], uint32_t present,
                                             int bx, int by, int sub)
 {
@@ -450,6 +450,19 @@ __device__ __forceinline__ mv_t score_block(const RegArgs &a, const mv_t (&cand)
 #pragma unroll
     for (int i = 0; i < RPL; ++i)
         cur[i] = *reinterpret_cast<const row_t *>(a.image1 + (size_t)(by + sub + i * LPB) * a.width + bx);
+    // DEDUP (throughput kernels): neighbouring blocks mostly carry the same MV, so a candidate whose
+    // MV already occurred earlier in the list re-uses that candidate's SAD instead of gathering the same
+    // image rows again.  first[k] = index of the first present candidate with the same MV.
+    int first[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        first[k] = k;
+        if constexpr (DEDUP) {
+#pragma unroll
+            for (int m = k - 1; m >= 0; --m)
+                if (((present >> m) & 1u) && cand[m] == cand[k]) first[k] = m;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         int x2 = bx + mv_x(cand[k]), y2 = by + mv_y(cand[k]);
@@ -457,9 +470,16 @@ __device__ __forceinline__ mv_t score_block(const RegArgs &a, const mv_t (&cand)
                         !(x2 < 0 || x2 > a.width - BS || y2 < 0 || y2 > a.height - BS);   // :578
         if (ok) inside |= 1u << k;
         else { x2 = bx; y2 = by; }                          // harmless address; result is discarded
+        if (!DEDUP || first[k] == k) {
 #pragma unroll
-        for (int i = 0; i < RPL; ++i)
-            win[k][i] = *reinterpret_cast<const row_t *>(a.image2 + (size_t)(y2 + sub + i * LPB) * a.width + x2);
+            for (int i = 0; i < RPL; ++i)
+                win[k][i] = *reinterpret_cast<const row_t *>(a.image2 + (size_t)(y2 + sub + i * LPB) * a.width + x2);
+        } else {                                            // duplicate: loads skipped under the exec mask
+#pragma unroll
+            for (int i = 0; i < RPL; ++i)
+#pragma unroll
+                for (int q = 0; q < NW; ++q) win[k][i].v[q] = 0;
+        }
     }
     // ---- SADs, reduced over the block's lanes ---------------------------------------------------
     float energy[9];
@@ -476,6 +496,15 @@ __device__ __forceinline__ mv_t score_block(const RegArgs &a, const mv_t (&cand)
             for (int o = LPB / 2; o > 0; o >>= 1) sad += __shfl_xor(sad, o);
         }
         energy[k] = (float)sad;
+    }
+    if constexpr (DEDUP) {
+#pragma unroll
+        for (int k = 1; k < 9; ++k) {
+            float e = energy[k];
+#pragma unroll
+            for (int m = 0; m < k; ++m) if (first[k] == m) e = energy[m];
+            energy[k] = e;
+        }
     }
     // calculate_smoothness (:623-644) with v_sad_u16 on bias-shifted halves: |u_m-u_k| + |v_m-v_k|
     int best = -1;
@@ -504,7 +533,7 @@ __device__ __forceinline__ mv_t score_block(const RegArgs &a, const mv_t (&cand)
 
 // Evaluate block (r, c) with its candidates read from global memory (one trip for all nine):
 // use_new = bit mask of the candidates read from `est` instead of `old_grid`.
-template <int BS, bool COHERENT>
+template <int BS, bool COHERENT, bool DEDUP = false>
 __device__ __forceinline__ mv_t eval_block(const RegArgs &a, int r, int c, int sub, uint32_t use_new)
 {
     mv_t cand[9];
@@ -519,7 +548,7 @@ __device__ __forceinline__ mv_t eval_block(const RegArgs &a, int r, int c, int s
         else
             cand[k] = a.old_grid[(size_t)(rs >> a.old_shift) * a.old_cols + (cs >> a.old_shift)];
     }
-    return score_block<BS>(a, cand, present, c * BS, r * BS, sub);
+    return score_block<BS, DEDUP>(a, cand, present, c * BS, r * BS, sub);
 }
 
 // Latency form of the evaluation, used where one wave walks a dependency chain (k_reg_solve and the
@@ -622,7 +651,7 @@ __global__ __launch_bounds__(256) void k_reg_pass1(RegArgs a)
     const int sub = (int)(t % LPB);
     if (g >= (long long)a.rows * a.cols) return;   // whole groups drop out together (LPB | 256)
     const int r = (int)(g / a.cols), c = (int)(g % a.cols);
-    const mv_t res = eval_block<BS, false>(a, r, c, sub, 0u);
+    const mv_t res = eval_block<BS, false, true>(a, r, c, sub, 0u);
     if (sub == 0) a.est[g] = res;
 }
 
