@@ -150,8 +150,14 @@ def main():
         return torch.as_tensor(v, device=torch.device("cuda", local_rank))
 
     gather_list = flows = None
+    work_stream = None
     if use_dist:
-        mf.set_stream(torch.cuda.current_stream().cuda_stream)
+        # an explicit stream: torch's default stream has handle 0, which bbme_set_stream reads as
+        # "create a private stream"
+        work_stream = torch.cuda.Stream(device=local_rank)
+        torch.cuda.set_stream(work_stream)
+        assert work_stream.cuda_stream != 0
+        mf.set_stream(work_stream.cuda_stream)
         cells_t = device_view(mf.cells_device_ptr(), (ph // 2, pw // 2), "<i4")     # packed int16 (dx, dy); NCCL has no int16
         if rank == 0:
             gather_list = [torch.empty_like(cells_t) for _ in range(world)]
