@@ -571,15 +571,17 @@ __device__ __forceinline__ mv_t eval_block_lanes(const RegArgs &a, int r, int c,
     const int rr = r + (int)((kRowCode >> (2 * k)) & 3u) - 1, cc = c + (int)((kColCode >> (2 * k)) & 3u) - 1;
     const bool present = k16 < 9 && rr >= 0 && rr < a.rows && cc >= 0 && cc < a.cols;
     const int rs = min(max(rr, 0), a.rows - 1), cs = min(max(cc, 0), a.cols - 1);
-    mv_t mv;
-    if ((use_new >> k) & 1u) mv = load_est<COHERENT>(a.est + (size_t)rs * a.cols + cs);
-    else mv = a.old_grid[(size_t)(rs >> a.old_shift) * a.old_cols + (cs >> a.old_shift)];
+    // one load instruction for all lanes (a divergent if / else would cost two memory trips): the
+    // already-updated inputs come from `est`, the others from `old_grid`, all through the coherent path
+    const mv_t *src = ((use_new >> k) & 1u) ? a.est + (size_t)rs * a.cols + cs
+                                            : a.old_grid + (size_t)(rs >> a.old_shift) * a.old_cols + (cs >> a.old_shift);
+    const mv_t mv = load_est<COHERENT>(src);
     const int bx = c * BS, by = r * BS;
     int x2 = bx + mv_x(mv), y2 = by + mv_y(mv);
     const bool inside = present && !(x2 < 0 || x2 > a.width - BS || y2 < 0 || y2 > a.height - BS);   // :578
     if (!inside) { x2 = bx; y2 = by; }
     // SAD of this lane's candidate: the rows are independent loads, issued back to back
-    uint32_t sad = 0;
+    uint32_t sad0 = 0, sad1 = 0;                              // two chains: v_sad_u8 results feed the next one
     const uint8_t *p1 = a.image1 + (size_t)by * a.width + bx;
     const uint8_t *p2 = a.image2 + (size_t)y2 * a.width + x2;
 #pragma unroll
@@ -587,8 +589,12 @@ __device__ __forceinline__ mv_t eval_block_lanes(const RegArgs &a, int r, int c,
         const row_t u = *reinterpret_cast<const row_t *>(p1 + (size_t)row * a.width);
         const row_t w = *reinterpret_cast<const row_t *>(p2 + (size_t)row * a.width);
 #pragma unroll
-        for (int q = 0; q < NW; ++q) sad = __builtin_amdgcn_sad_u8(u.v[q] & kMask, w.v[q] & kMask, sad);
+        for (int q = 0; q < NW; ++q) {
+            if ((row + q) & 1) sad1 = __builtin_amdgcn_sad_u8(u.v[q] & kMask, w.v[q] & kMask, sad1);
+            else sad0 = __builtin_amdgcn_sad_u8(u.v[q] & kMask, w.v[q] & kMask, sad0);
+        }
     }
+    const uint32_t sad = sad0 + sad1;
     // smoothness: sum over the present candidates of |u_m - u_k| + |v_m - v_k| (:637-641)
     const int lane = (int)(threadIdx.x & 63u);
     const int base = lane & ~15;
