@@ -53,6 +53,8 @@ SIGNATURES = {
     "bbme_flo_read": (C.c_int, [C.c_char_p, _P(C.c_int), _P(C.c_int), _P(_P(C.c_float))]),
     "bbme_flo_write": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_void_p]),
     "bbme_calculate_mse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _P(C.c_double)]),
+    "bbme_motion_to_color": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, _P(C.c_float)]),
+    "bbme_ppm_write_bgr": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_void_p]),
     "bbme_subsample_div4": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_int]),
     "bbme_free": (None, [C.c_void_p]),
     "bbme_spiral_host": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, _P(C.c_int)]),

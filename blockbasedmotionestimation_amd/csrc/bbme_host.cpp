@@ -325,6 +325,94 @@ double calculate_mse(const float *gtruth, const float *flow, int width, int heig
     return error / (double)count;
 }
 
+// ---- Flow::MotionToColor / computeColor / makecolorwheel (rw_flow.cpp:202-307) -------------
+// The Middlebury colour wheel: 55 hues in six transitions whose lengths follow perceptual
+// similarity.  Entry k of a transition of length n from colour A towards B moves one channel
+// by 255*i/n (integer division), exactly as the reference's six loops do.
+namespace {
+struct ColorWheel {
+    static constexpr int kCols = 15 + 6 + 4 + 11 + 13 + 6;
+    int rgb[kCols][3];
+    ColorWheel()
+    {
+        static const int len[6] = {15, 6, 4, 11, 13, 6};          // RY YG GC CB BM MR
+        static const int moving[6] = {1, 0, 2, 1, 0, 2};          // channel that changes
+        static const int rising[6] = {1, 0, 1, 0, 1, 0};          // ... upwards or downwards
+        static const int base[6][3] = {{255, 0, 0}, {255, 255, 0}, {0, 255, 0}, {0, 255, 255}, {0, 0, 255}, {255, 0, 255}};
+        int k = 0;
+        for (int t = 0; t < 6; ++t)
+            for (int i = 0; i < len[t]; ++i, ++k) {
+                for (int c = 0; c < 3; ++c) rgb[k][c] = base[t][c];
+                const int step = 255 * i / len[t];
+                rgb[k][moving[t]] = rising[t] ? step : 255 - step;
+            }
+    }
+};
+const ColorWheel g_wheel;
+
+// computeColor (rw_flow.cpp:251-275): hue from the angle, saturation from the radius; all float
+// except the division by pi and the final scaling, which the reference's expressions do in double.
+inline void compute_color(float fx, float fy, uint8_t *bgr)
+{
+    const int ncols = ColorWheel::kCols;
+    const float rad = std::sqrt(fx * fx + fy * fy);
+    const float a = (float)(std::atan2(-fy, -fx) / 3.14159265358979323846);   // M_PI
+    const float fk = (a + 1.0f) / 2.0f * (float)(ncols - 1);
+    const int k0 = (int)fk;
+    const int k1 = (k0 + 1) % ncols;
+    const float f = fk - (float)k0;
+    for (int b = 0; b < 3; ++b) {
+        const float col0 = (float)g_wheel.rgb[k0][b] / 255.0f;
+        const float col1 = (float)g_wheel.rgb[k1][b] / 255.0f;
+        float col = (1 - f) * col0 + f * col1;
+        if (rad <= 1) col = 1 - rad * (1 - col);               // increase saturation with radius
+        else col = (float)(col * .75);                          // out of range
+        bgr[2 - b] = (uint8_t)(int)(255.0 * col);
+    }
+}
+}  // namespace
+
+void motion_to_color(const float *flow, int width, int height, float maxmotion, uint8_t *bgr, float range[5])
+{
+    float maxx = -999, maxy = -999, minx = 999, miny = 999, maxrad = -1;
+    const size_t n = (size_t)width * height;
+    for (size_t i = 0; i < n; ++i) {
+        const float fx = flow[2 * i], fy = flow[2 * i + 1];
+        if (unknown_flow(fx, fy)) continue;
+        maxx = maxx > fx ? maxx : fx;
+        maxy = maxy > fy ? maxy : fy;
+        minx = minx < fx ? minx : fx;
+        miny = miny < fy ? miny : fy;
+        const float rad = std::sqrt(fx * fx + fy * fy);
+        maxrad = maxrad > rad ? maxrad : rad;
+    }
+    if (range) { range[0] = maxrad; range[1] = minx; range[2] = maxx; range[3] = miny; range[4] = maxy; }
+    if (maxmotion > 0) maxrad = maxmotion;                      // i.e. specified by the caller
+    if (maxrad == 0) maxrad = 1;                                // flow == 0 everywhere
+    for (size_t i = 0; i < n; ++i) {
+        const float fx = flow[2 * i], fy = flow[2 * i + 1];
+        uint8_t *pix = bgr + 3 * i;
+        if (unknown_flow(fx, fy)) pix[0] = pix[1] = pix[2] = 0;
+        else compute_color(fx / maxrad, fy / maxrad, pix);
+    }
+}
+
+int ppm_write_bgr(const char *filename, int width, int height, const uint8_t *bgr)
+{
+    FILE *f = fopen(filename, "wb");
+    if (!f) return fail(BBME_ERR_IO, "ppm_write: could not open %s", filename);
+    fprintf(f, "P6\n%d %d\n255\n", width, height);
+    std::vector<uint8_t> row((size_t)width * 3);
+    bool ok = true;
+    for (int y = 0; y < height && ok; ++y) {
+        const uint8_t *s = bgr + (size_t)y * width * 3;
+        for (int x = 0; x < width; ++x) { row[3 * x] = s[3 * x + 2]; row[3 * x + 1] = s[3 * x + 1]; row[3 * x + 2] = s[3 * x]; }
+        ok = fwrite(row.data(), 1, row.size(), f) == row.size();
+    }
+    if (fclose(f) != 0) ok = false;
+    return ok ? BBME_OK : fail(BBME_ERR_IO, "ppm_write: problem writing %s", filename);
+}
+
 void subsample_div4(const float *flow_padded, int padded_width, int padded_height,
                     int pad_x, int pad_y, float *out, int out_width)
 {
@@ -400,6 +488,21 @@ int bbme_calculate_mse(const float *gtruth, const float *flow, int width, int he
         return bbme::fail(BBME_ERR_INVALID, "bbme_calculate_mse: bad arguments");
     *out = bbme::calculate_mse(gtruth, flow, width, height);
     return BBME_OK;
+}
+
+int bbme_motion_to_color(const float *flow, int width, int height, float maxmotion, uint8_t *bgr, float *range)
+{
+    if (!flow || !bgr || width < 1 || height < 1)
+        return bbme::fail(BBME_ERR_INVALID, "bbme_motion_to_color: bad arguments");
+    bbme::motion_to_color(flow, width, height, maxmotion, bgr, range);
+    return BBME_OK;
+}
+
+int bbme_ppm_write_bgr(const char *filename, int width, int height, const uint8_t *bgr)
+{
+    if (!filename || !bgr || width < 1 || height < 1)
+        return bbme::fail(BBME_ERR_INVALID, "bbme_ppm_write_bgr: bad arguments");
+    return bbme::ppm_write_bgr(filename, width, height, bgr);
 }
 
 int bbme_subsample_div4(const float *flow_padded, int padded_width, int padded_height,

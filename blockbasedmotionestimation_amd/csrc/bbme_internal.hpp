@@ -49,6 +49,8 @@ SearchPlan plan_search(int range, int block_size, int max_strip);
 int flo_read(const char *filename, int *width, int *height, float **data);
 int flo_write(const char *filename, int width, int height, const float *data);
 double calculate_mse(const float *gtruth, const float *flow, int width, int height);
+void motion_to_color(const float *flow, int width, int height, float maxmotion, uint8_t *bgr, float range[5]);
+int ppm_write_bgr(const char *filename, int width, int height, const uint8_t *bgr);
 void subsample_div4(const float *flow_padded, int padded_width, int padded_height,
                     int pad_x, int pad_y, float *out, int out_width);
 

@@ -1,7 +1,7 @@
 // bbme_main.cpp -- the reference's driver (main_class.cpp:6-85) as a real command line.
 //
-//   bbme_cli frame10.pgm frame11.pgm [--gt flow10.flo] [--out flow.flo] [--levels N] [--block B]
-//            [--search S] [--no-upsample] [--device D]
+//   bbme_cli frame10.pgm frame11.pgm [--gt flow10.flo] [--out flow.flo] [--color flow.ppm] [--levels N]
+//            [--block B] [--search S] [--no-upsample] [--device D]
 //
 // Sequence of main_class.cpp: read two grey frames (:24,26; binary PGM here, the image has no
 // libpng), 4x bilinear up-sampling (:32-33), MF::MF (:45), timed calcMotionBlockMatching (:47-55),
@@ -44,7 +44,7 @@ static bool read_pgm(const char *path, bbme::Image8 &img)
 
 int main(int argc, char **argv)
 {
-    const char *f1 = nullptr, *f2 = nullptr, *gt = nullptr, *out = nullptr;
+    const char *f1 = nullptr, *f2 = nullptr, *gt = nullptr, *out = nullptr, *color = nullptr;
     int levels = 4, block = 32, search = 64, device = 0;
     bool upsample = true;
     for (int i = 1; i < argc; ++i) {
@@ -52,6 +52,7 @@ int main(int argc, char **argv)
         auto next = [&]() -> const char * { if (i + 1 >= argc) { fprintf(stderr, "%s needs a value\n", a.c_str()); exit(2); } return argv[++i]; };
         if (a == "--gt") gt = next();
         else if (a == "--out") out = next();
+        else if (a == "--color") color = next();
         else if (a == "--levels") levels = atoi(next());
         else if (a == "--block") block = atoi(next());
         else if (a == "--search") search = atoi(next());
@@ -62,8 +63,8 @@ int main(int argc, char **argv)
         else { fprintf(stderr, "unexpected argument %s\n", argv[i]); return 2; }
     }
     if (!f1 || !f2 || levels < 1 || levels > BBME_MAX_LEVELS) {
-        fprintf(stderr, "usage: bbme_cli frame1.pgm frame2.pgm [--gt gt.flo] [--out flow.flo] [--levels N] "
-                        "[--block B] [--search S] [--no-upsample] [--device D]\n");
+        fprintf(stderr, "usage: bbme_cli frame1.pgm frame2.pgm [--gt gt.flo] [--out flow.flo] [--color flow.ppm] "
+                        "[--levels N] [--block B] [--search S] [--no-upsample] [--device D]\n");
         return 2;
     }
     try {
@@ -96,6 +97,11 @@ int main(int argc, char **argv)
         }
         (void)scale;
         Flow file;
+        if (color) {                                   // main_class.cpp:73-75 (flow.png there)
+            bbme::ImageBGR flow_img;
+            file.MotionToColor(subpix, flow_img, -1);
+            file.ShowImage(flow_img, color);
+        }
         if (out) file.WriteFlowFile(subpix, out);
         if (gt) {
             bbme::ImageFlow gtruth;

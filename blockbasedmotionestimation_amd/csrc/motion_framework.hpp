@@ -57,6 +57,16 @@ struct ImageFlow {
     const float *at(int y, int x) const { return &data[2 * ((size_t)y * cols + x)]; }
 };
 
+// three-band 8-bit image, B,G,R interleaved (the reference's CV_8UC3 cv::Mat)
+struct ImageBGR {
+    int rows = 0, cols = 0;
+    std::vector<uint8_t> data;
+    ImageBGR() = default;
+    ImageBGR(int r, int c) : rows(r), cols(c), data((size_t)r * c * 3) {}
+    uint8_t *at(int y, int x) { return &data[3 * ((size_t)y * cols + x)]; }
+    const uint8_t *at(int y, int x) const { return &data[3 * ((size_t)y * cols + x)]; }
+};
+
 // cv::resize(img, img, cv::Size(), 4, 4, cv::INTER_LINEAR) of main_class.cpp:32-33
 inline Image8 resize_x4(const Image8 &src)
 {

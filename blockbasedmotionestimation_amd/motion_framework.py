@@ -71,6 +71,15 @@ class MF:
         self.close()
 
     # -- inputs ---------------------------------------------------------------------------
+    def set_frames(self, image1, image2):
+        """A new pair of the same size into this context (host arrays): what a second MF::MF would do,
+        without re-allocating the level state or re-capturing the launch graph."""
+        image1 = np.ascontiguousarray(image1, dtype=np.uint8)
+        image2 = np.ascontiguousarray(image2, dtype=np.uint8)
+        if image1.shape != (self.orig_height, self.orig_width) or image2.shape != image1.shape:
+            raise _capi.BbmeError(_capi.ERR_INVALID, "frames must keep the size the context was created for")
+        _capi.check(self._lib.bbme_set_frames_host(self._ctx, image1.ctypes.data, image2.ctypes.data, self.orig_width))
+
     def set_frames_device(self, image1, image2):
         """Frames already in HBM (torch uint8 CUDA tensors, H x W): padding + pyramid on the GPU."""
         assert image1.is_cuda and image2.is_cuda and image1.dtype.itemsize == 1

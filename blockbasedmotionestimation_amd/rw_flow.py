@@ -1,7 +1,8 @@
 """Python mirror of the reference's Flow class (rw_flow.h:9-38) over the C-ABI.
 
-ReadFlowFile / WriteFlowFile / CalculateMSE keep the reference's names and argument order.
-MotionToColor and ShowImage (visualisation, rw_flow.cpp:202-307,334-340) are out of scope.
+ReadFlowFile / WriteFlowFile / MotionToColor / CalculateMSE keep the reference's names and argument
+order.  ShowImage (rw_flow.cpp:334-340) opens a GUI window and writes flowimg.png in the reference;
+here it only writes the image, as binary PPM (there is neither a GUI nor a PNG codec in this image).
 Errors the reference reports with a message and exit(1) raise BbmeError instead.
 """
 import ctypes as C
@@ -41,6 +42,29 @@ class Flow:
         out = C.c_double()
         _capi.check(_capi.lib().bbme_calculate_mse(g.ctypes.data, f.ctypes.data, g.shape[1], g.shape[0], C.byref(out)))
         return out.value
+
+
+    def MotionToColor(self, input_img, maxmotion=-1.0, verbose=True):
+        """Flow::MotionToColor (rw_flow.cpp:202-249): Middlebury colour coding -> (H, W, 3) uint8, B,G,R
+        as in the reference's CV_8UC3 output.  Prints the reference's "max motion" line unless verbose=False."""
+        f = np.ascontiguousarray(input_img, np.float32)
+        if f.ndim != 3 or f.shape[2] != 2:
+            raise _capi.BbmeError(_capi.ERR_INVALID, "MotionToColor: image must have 2 bands")
+        out = np.empty((f.shape[0], f.shape[1], 3), np.uint8)
+        rng = (C.c_float * 5)()
+        _capi.check(_capi.lib().bbme_motion_to_color(f.ctypes.data, f.shape[1], f.shape[0], float(maxmotion),
+                                                     out.ctypes.data, rng))
+        self.last_range = tuple(rng)
+        if verbose:
+            print("max motion: %.4f  motion range: u = %.3f .. %.3f;  v = %.3f .. %.3f" % self.last_range)
+        return out
+
+    def ShowImage(self, flow_img, filename="flowimg.ppm"):
+        """Flow::ShowImage (rw_flow.cpp:334-340) without the window: writes the B,G,R image as binary PPM."""
+        img = np.ascontiguousarray(flow_img, np.uint8)
+        if img.ndim != 3 or img.shape[2] != 3:
+            raise _capi.BbmeError(_capi.ERR_INVALID, "ShowImage: image must have 3 bands")
+        _capi.check(_capi.lib().bbme_ppm_write_bgr(os.fsencode(filename), img.shape[1], img.shape[0], img.ctypes.data))
 
 
 def subsample_div4(flow_padded, pad_x, pad_y, out_width, out_height):

@@ -16,6 +16,47 @@ def shard_pairs(n_pairs, rank, world_size):
     return list(range(rank, n_pairs, world_size))
 
 
+def estimate_pairs_pipelined(pairs, search_size, block_size, device=0, in_flight=4):
+    """All pairs of `pairs` (a list of (frame1, frame2), equal sizes) on ONE GPU, `in_flight` of them at a time.
+
+    One context per slot, created once (level state, launch graph) and re-used round-robin; every
+    context has its own stream, so while one pair's regulariser walks its dependency chains the
+    chip works on the others.  Returns the unpadded (H, W, 2) float32 fields in input order.
+    The result of a pair does not depend on what else is in flight (tests/test_gpu_parity.py).
+    """
+    from .motion_framework import MF
+    if not pairs:
+        return []
+    slots = []
+    out = [None] * len(pairs)
+    pending = []                                           # (slot, pair index), oldest first
+
+    def collect():
+        slot, idx = pending.pop(0)
+        mf = slots[slot]
+        h, w = pairs[idx][0].shape
+        flow = mf.get_flow()                               # waits for this context's stream only
+        out[idx] = np.ascontiguousarray(flow[mf.padding_y:mf.padding_y + h, mf.padding_x:mf.padding_x + w])
+
+    try:
+        for idx, (f1, f2) in enumerate(pairs):
+            if len(slots) < max(1, in_flight):
+                slots.append(MF(f1, f2, search_size, block_size, len(block_size), device=device))
+                slot = len(slots) - 1
+            else:
+                slot = pending[0][0]
+                collect()
+                slots[slot].set_frames(f1, f2)
+            slots[slot].estimate_async()
+            pending.append((slot, idx))
+        while pending:
+            collect()
+    finally:
+        for mf in slots:
+            mf.close()
+    return out
+
+
 def _gpu_compute(search_size, block_size, device):
     from .motion_framework import MF
 

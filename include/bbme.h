@@ -74,6 +74,14 @@ int bbme_flo_read(const char *filename, int *width, int *height, float **data);
 int bbme_flo_write(const char *filename, int width, int height, const float *data);
 /* Flow::CalculateMSE (rw_flow.cpp:309-332): mean end-point error over known GT pixels. */
 int bbme_calculate_mse(const float *gtruth, const float *flow, int width, int height, double *out);
+/* Flow::MotionToColor (rw_flow.cpp:202-249, with computeColor :251-275 and makecolorwheel :277-300):
+ * Middlebury colour coding of a flow field.  bgr = width*height*3 bytes, B,G,R per pixel as in the
+ * reference's CV_8UC3 image; unknown pixels black; maxmotion > 0 overrides the normalising radius.
+ * range (may be NULL) receives {max radius, min u, max u, min v, max v} of the known pixels, the
+ * numbers the reference prints. */
+int bbme_motion_to_color(const float *flow, int width, int height, float maxmotion, uint8_t *bgr, float *range);
+/* What Flow::ShowImage (rw_flow.cpp:334-340) keeps on disk, as binary PPM (no PNG codec, no GUI here). */
+int bbme_ppm_write_bgr(const char *filename, int width, int height, const uint8_t *bgr);
 /* main_class.cpp:58-70: strip padding, every 4th pixel, divide by 4. */
 int bbme_subsample_div4(const float *flow_padded, int padded_width, int padded_height,
                         int pad_x, int pad_y, float *out, int out_width, int out_height);

@@ -299,6 +299,31 @@ def test_errors_through_the_boundary(bbme):
     mf.close()
 
 
+def test_pipelined_sequence_matches_oracle_per_pair(bbme, oracle):
+    """A sequence on one GPU with several pairs in flight (contexts re-used round-robin with new frames):
+    every pair's field is the oracle's, whatever else is running beside it."""
+    from blockbasedmotionestimation_amd.sequence import estimate_pairs_pipelined
+    search, block = [40, 40, 40], [8, 8, 8]
+    pairs = [bbme.synth_pair(328, 200, 4200 + i, max_motion=10)[:2] for i in range(7)]
+    expect = []
+    for f1, f2 in pairs:
+        omf = oracle.OracleMF(f1, f2, search, block)
+        full = omf.calc_motion_block_matching()
+        py, px = omf.padding_y, omf.padding_x
+        expect.append(full[py:py + 200, px:px + 328])
+        omf.close()
+    for k in (1, 3, 16):
+        got = estimate_pairs_pipelined(pairs, search, block, in_flight=k)
+        assert len(got) == len(pairs)
+        for g, e in zip(got, expect):
+            assert g.shape == (200, 328, 2) and np.array_equal(g, e)
+    assert estimate_pairs_pipelined([], search, block) == []
+    mf = bbme.MF(pairs[0][0], pairs[0][1], search, block, 3)
+    with pytest.raises(bbme.BbmeError):
+        mf.set_frames(pairs[0][0][:100], pairs[0][1][:100])
+    mf.close()
+
+
 @pytest.mark.parametrize("cfg", ["cfg2_1080p", "cfg3_4k", "cfg4_4k_b8"])
 def test_full_size_properties(bbme, cfg):
     """BASELINE.json's full sizes, through properties that need no oracle run:
