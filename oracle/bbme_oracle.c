@@ -706,6 +706,89 @@ double orc_calculate_mse(const float *gtruth, const float *flow, int width, int 
     return error;
 }
 
+/* ---- Flow::MotionToColor and its helpers (rw_flow.cpp:202-307) ---------------------------- */
+static int orc_ncols = 0;
+static int orc_colorwheel[60][3];                                     /* MAXCOLS 60, rw_flow.h */
+
+static void orc_setcols(int r, int g, int b, int k)                   /* :302-307 */
+{
+    orc_colorwheel[k][0] = r; orc_colorwheel[k][1] = g; orc_colorwheel[k][2] = b;
+}
+
+static void orc_makecolorwheel(void)                                  /* :277-300 */
+{
+    const int RY = 15, YG = 6, GC = 4, CB = 11, BM = 13, MR = 6;
+    int k = 0;
+    orc_ncols = RY + YG + GC + CB + BM + MR;
+    for (int i = 0; i < RY; i++) orc_setcols(255, 255 * i / RY, 0, k++);
+    for (int i = 0; i < YG; i++) orc_setcols(255 - 255 * i / YG, 255, 0, k++);
+    for (int i = 0; i < GC; i++) orc_setcols(0, 255, 255 * i / GC, k++);
+    for (int i = 0; i < CB; i++) orc_setcols(0, 255 - 255 * i / CB, 255, k++);
+    for (int i = 0; i < BM; i++) orc_setcols(255 * i / BM, 0, 255, k++);
+    for (int i = 0; i < MR; i++) orc_setcols(255, 0, 255 - 255 * i / MR, k++);
+}
+
+/* :251-275.  The reference is C++: sqrt / atan2 of floats are the float overloads; the division
+ * by M_PI and the final 255.0 * col are double expressions; `col *= .75` is a double product
+ * rounded back to float. */
+/* vendored != 0 selects the expression types of the Middlebury original the reference vendors
+ * (middlebury/flow-code/colorcode.cpp:59,65-66: `(a + 1.0) / 2.0 * (ncols-1)` and `/ 255.0` are double
+ * there, float `1.0f`, `2.0f`, `255.0f` in rw_flow.cpp:258,264-265).  That flavour exists only so that
+ * this restatement can be pinned bit for bit against the compiled vendored file (oracle/_ref). */
+static void orc_compute_color(float fx, float fy, unsigned char *pix, int vendored)
+{
+    if (orc_ncols == 0) orc_makecolorwheel();
+    float rad = sqrtf(fx * fx + fy * fy);                             /* :256 */
+    float a = (float)((double)atan2f(-fy, -fx) / 3.14159265358979323846);   /* :257 */
+    float fk = vendored ? (float)(((double)a + 1.0) / 2.0 * (double)(orc_ncols - 1))
+                        : (a + 1.0f) / 2.0f * (float)(orc_ncols - 1); /* :258 */
+    int k0 = (int)fk;
+    int k1 = (k0 + 1) % orc_ncols;
+    float f = fk - (float)k0;
+    for (int b = 0; b < 3; b++) {
+        float col0 = vendored ? (float)((double)orc_colorwheel[k0][b] / 255.0) : (float)orc_colorwheel[k0][b] / 255.0f;   /* :264 */
+        float col1 = vendored ? (float)((double)orc_colorwheel[k1][b] / 255.0) : (float)orc_colorwheel[k1][b] / 255.0f;
+        float col = (1 - f) * col0 + f * col1;
+        if (rad <= 1) col = 1 - rad * (1 - col);                      /* :268 */
+        else col = (float)((double)col * .75);                        /* :270 */
+        pix[2 - b] = (unsigned char)(int)(255.0 * (double)col);       /* :271, B,G,R order */
+    }
+}
+
+void orc_motion_to_color_flavour(const float *flow, int width, int height, float maxmotion,
+                                 unsigned char *bgr, float *range, int vendored);
+
+void orc_motion_to_color(const float *flow, int width, int height, float maxmotion,
+                         unsigned char *bgr, float *range)            /* :202-249 */
+{
+    orc_motion_to_color_flavour(flow, width, height, maxmotion, bgr, range, 0);
+}
+
+void orc_motion_to_color_flavour(const float *flow, int width, int height, float maxmotion,
+                                 unsigned char *bgr, float *range, int vendored)
+{
+    float maxx = -999, maxy = -999, minx = 999, miny = 999, maxrad = -1;
+    for (int i = 0; i < height; i++)
+        for (int j = 0; j < width; j++) {
+            float fx = flow[2 * ((size_t)i * width + j)], fy = flow[2 * ((size_t)i * width + j) + 1];
+            if (unknown_flow(fx, fy)) continue;
+            maxx = maxx > fx ? maxx : fx;  maxy = maxy > fy ? maxy : fy;      /* __max / __min :214-217 */
+            minx = minx < fx ? minx : fx;  miny = miny < fy ? miny : fy;
+            float rad = sqrtf(fx * fx + fy * fy);
+            maxrad = maxrad > rad ? maxrad : rad;
+        }
+    if (range) { range[0] = maxrad; range[1] = minx; range[2] = maxx; range[3] = miny; range[4] = maxy; }   /* printed :223 */
+    if (maxmotion > 0) maxrad = maxmotion;                            /* :225 */
+    if (maxrad == 0) maxrad = 1;                                      /* :228 */
+    for (int i = 0; i < height; i++)
+        for (int j = 0; j < width; j++) {
+            float fx = flow[2 * ((size_t)i * width + j)], fy = flow[2 * ((size_t)i * width + j) + 1];
+            unsigned char *pix = bgr + 3 * ((size_t)i * width + j);
+            if (unknown_flow(fx, fy)) pix[0] = pix[1] = pix[2] = 0;   /* :241-243 */
+            else orc_compute_color(fx / maxrad, fy / maxrad, pix, vendored);   /* :245 */
+        }
+}
+
 void orc_subsample_div4(const float *flow_padded, int padded_width, int padded_height,
                         int pad_x, int pad_y, float *out, int out_width, int out_height)
 {

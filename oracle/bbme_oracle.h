@@ -96,6 +96,12 @@ int  orc_spiral_walk(int shift, int *dx, int *dy, int cap);
 int    orc_flo_read(const char *filename, int *width, int *height, float **data);
 int    orc_flo_write(const char *filename, int width, int height, const float *data); /* :139-200 */
 double orc_calculate_mse(const float *gtruth, const float *flow, int width, int height); /* :309-332 */
+/* Flow::MotionToColor (rw_flow.cpp:202-307): bgr = width*height*3, range[5] = max radius, min/max u, min/max v */
+void   orc_motion_to_color(const float *flow, int width, int height, float maxmotion,
+                           unsigned char *bgr, float *range);
+/* vendored = 1: expression types of middlebury/flow-code/colorcode.cpp instead of rw_flow.cpp's (pinning only) */
+void   orc_motion_to_color_flavour(const float *flow, int width, int height, float maxmotion,
+                                   unsigned char *bgr, float *range, int vendored);
 /* main_class.cpp:58-70: strip padding, take every 4th pixel, divide by 4 */
 void   orc_subsample_div4(const float *flow_padded, int padded_width, int padded_height,
                           int pad_x, int pad_y, float *out, int out_width, int out_height);

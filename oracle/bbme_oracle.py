@@ -269,6 +269,19 @@ def calculate_mse(gtruth, flow):
     return lib().orc_calculate_mse(g.ctypes.data, f.ctypes.data, g.shape[1], g.shape[0])
 
 
+def motion_to_color(flow, maxmotion=-1.0, vendored=False):
+    """Flow::MotionToColor -> ((H, W, 3) uint8 B,G,R, (max radius, min u, max u, min v, max v)).
+    vendored=True: expression types of the vendored Middlebury colorcode.cpp (pinning only)."""
+    f = np.ascontiguousarray(flow, np.float32)
+    out = np.empty((f.shape[0], f.shape[1], 3), np.uint8)
+    rng = (C.c_float * 5)()
+    fn = lib().orc_motion_to_color_flavour
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.POINTER(C.c_float), C.c_int]
+    fn(f.ctypes.data, f.shape[1], f.shape[0], float(maxmotion), out.ctypes.data, rng, int(bool(vendored)))
+    return out, tuple(rng)
+
+
 def subsample_div4(flow_padded, pad_x, pad_y, out_width, out_height):
     f = np.ascontiguousarray(flow_padded, np.float32)
     out = np.zeros((out_height, out_width, 2), np.float32)

@@ -13,6 +13,11 @@
 3. gt_stats.json -- known answers computed with the reference's own reader on the 8 ground-truth
    files it ships (size, unknown-pixel count, sums, sha256), plus gt_Venus_flow10.flo copied as
    data (smallest GT file) so the GPU box can run the known-answer test without /root/reference.
+4. color_ref.npz -- colour coding made by the REFERENCE's own vendored colour-wheel code
+   (middlebury/flow-code/colorcode.cpp computeColor, compiled into oracle/_ref/flo_ref, called by
+   oracle/ref_flo_driver.cpp): Venus ground truth with the automatic radius and with maxmotion 3.5
+   (exercises the out-of-range branch), and a synthetic wheel field (all angles, radii 0..1.5,
+   some unknown pixels).  gt_stats.json also gets the sha256 of that output for all 8 GT files.
 """
 import hashlib
 import json
@@ -67,6 +72,22 @@ def make_hotpath(name, w, h, search, block, seed, mm):
     print(name, "stages:", len(stages), "flow", data["flow"].shape)
 
 
+def wheel_field():
+    """All angles and radii 0 .. 1.5 of the normalising radius, a band of unknown pixels, signed zeros."""
+    y, x = np.mgrid[-60:61, -90:91].astype(np.float32)
+    f = np.stack([x * np.float32(0.37), y * np.float32(0.53)], -1).astype(np.float32)
+    f[5:9, :, 0] = 1e10                                    # unknown (rw_flow.cpp:39-43)
+    f[60, :, 1] = -0.0                                     # atan2 of a negative zero: the +pi / -pi seam
+    return f
+
+
+def color_by_reference(flo_ref, flo_path, shape, maxmotion=None):
+    out = os.path.join("/tmp", "bbme_color_ref.bgr")
+    cmd = [flo_ref, "color", flo_path, out] + ([repr(maxmotion)] if maxmotion else [])
+    subprocess.check_call(cmd)
+    return np.fromfile(out, np.uint8).reshape(shape[0], shape[1], 3)
+
+
 def main():
     O.build(force=True)
     for name, cfg in CASES.items():
@@ -81,7 +102,20 @@ def main():
         w, h, unk, su, sv = subprocess.check_output([flo_ref, "stats", p]).decode().split()
         stats[seq] = {"width": int(w), "height": int(h), "unknown": int(unk), "sum_u": float(su), "sum_v": float(sv),
                       "bytes": os.path.getsize(p), "sha256": hashlib.sha256(open(p, "rb").read()).hexdigest()}
+        shape = (int(h), int(w))
+        stats[seq]["color_sha256"] = hashlib.sha256(color_by_reference(flo_ref, p, shape).tobytes()).hexdigest()
     json.dump(stats, open(os.path.join(HERE, "gt_stats.json"), "w"), indent=1, sort_keys=True)
+    venus = os.path.join(gt_dir, "Venus", "flow10.flo")
+    vshape = (stats["Venus"]["height"], stats["Venus"]["width"])
+    wheel = wheel_field()
+    wheel_path = "/tmp/bbme_wheel.flo"
+    O.flo_write(wheel_path, wheel)
+    np.savez_compressed(os.path.join(HERE, "color_ref.npz"),
+                        venus_auto=color_by_reference(flo_ref, venus, vshape),
+                        venus_max3p5=color_by_reference(flo_ref, venus, vshape, 3.5),
+                        wheel_flow=wheel,
+                        wheel_auto=color_by_reference(flo_ref, wheel_path, wheel.shape),
+                        wheel_max40=color_by_reference(flo_ref, wheel_path, wheel.shape, 40.0))
     shutil.copyfile(os.path.join(gt_dir, "Venus", "flow10.flo"), os.path.join(HERE, "gt_Venus_flow10.flo"))
     os.chmod(os.path.join(HERE, "gt_Venus_flow10.flo"), 0o644)
     print("gt stats:", {k: (v["width"], v["height"], v["unknown"]) for k, v in stats.items()})

@@ -111,6 +111,48 @@ def test_flow_class_codec_and_epe(bbme, oracle, tmp_path):
     assert np.array_equal(sub, oracle.subsample_div4(np.arange(64 * 48 * 2, dtype=np.float32).reshape(48, 64, 2), 4, 8, 14, 8))
 
 
+def test_motion_to_color_equals_oracle(bbme, oracle, tmp_path, capsys):
+    """Flow::MotionToColor / ShowImage of the product against the oracle (bit-exact) and against the image the
+    reference's vendored colorcode.cpp made (tests/golden/color_ref.npz; one level in a handful of channels,
+    see test_colour_coding_pinned_by_reference_colorcode)."""
+    flow = bbme.Flow()
+    ref = np.load(os.path.join(GOLDEN, "color_ref.npz"), allow_pickle=False)
+    venus = flow.ReadFlowFile(os.path.join(GOLDEN, "gt_Venus_flow10.flo"))
+    rng = np.random.default_rng(21)
+    noisy = (rng.normal(0, 6, (97, 131, 2))).astype(np.float32)
+    noisy[3, 4] = np.nan
+    noisy[10:12] = 1.666666752e9
+    noisy[20, 20] = (-0.0, 0.0)
+    cases = [(venus, -1.0, "venus_auto"), (venus, 3.5, "venus_max3p5"), (ref["wheel_flow"], -1.0, "wheel_auto"),
+             (ref["wheel_flow"], 40.0, "wheel_max40"), (noisy, -1.0, None), (noisy, 2.0, None),
+             (np.zeros((4, 5, 2), np.float32), -1.0, None)]
+    for f, maxmotion, key in cases:
+        got = flow.MotionToColor(f, maxmotion, verbose=False)
+        exp, exp_range = oracle.motion_to_color(f, maxmotion)
+        assert got.dtype == np.uint8 and got.shape == f.shape[:2] + (3,)
+        assert np.array_equal(got, exp)
+        assert flow.last_range == exp_range
+        if key is not None:
+            d = np.abs(got.astype(np.int16) - ref[key].astype(np.int16))
+            assert d.max() <= 1 and np.count_nonzero(d) <= 1e-4 * d.size
+    flow.MotionToColor(venus, -1)
+    assert capsys.readouterr().out == "max motion: 9.3750  motion range: u = -9.375 .. 7.000;  v = 0.000 .. 0.000\n"
+    img = flow.MotionToColor(ref["wheel_flow"], verbose=False)
+    out = tmp_path / "flowimg.ppm"
+    flow.ShowImage(img, str(out))
+    raw = out.read_bytes()
+    head = b"P6\n181 121\n255\n"
+    assert raw.startswith(head) and len(raw) == len(head) + img.size
+    assert np.array_equal(np.frombuffer(raw[len(head):], np.uint8).reshape(img.shape), img[..., ::-1])
+    with pytest.raises(bbme.BbmeError):
+        flow.MotionToColor(np.zeros((4, 4, 3), np.float32))
+    with pytest.raises(bbme.BbmeError):
+        flow.ShowImage(np.zeros((4, 4), np.uint8), str(out))
+    with pytest.raises(bbme.BbmeError) as e:
+        flow.ShowImage(img, str(tmp_path / "no_such_dir" / "x.ppm"))
+    assert e.value.status == -6
+
+
 def test_flow_errors_raise_instead_of_exit(bbme, tmp_path):
     flow = bbme.Flow()
     good = open(os.path.join(GOLDEN, "flo_ramp_ref.flo"), "rb").read()

@@ -165,6 +165,50 @@ def test_gt_known_answers(oracle):
     assert oracle.calculate_mse(f, g) == pytest.approx(5.0, abs=1e-5)
 
 
+def test_colour_coding_pinned_by_reference_colorcode(oracle):
+    """Flow::MotionToColor.  tests/golden/color_ref.npz was made by the reference's own vendored colour-wheel
+    code (middlebury/flow-code/colorcode.cpp, compiled into oracle/_ref).  The oracle's `vendored` flavour
+    (that file's double sub-expressions) must reproduce it bit for bit; the rw_flow.cpp flavour (float
+    sub-expressions, rw_flow.cpp:258,264-265 -- the one the product follows) may differ from it by one level
+    in a handful of channel values and nowhere else."""
+    ref = np.load(os.path.join(GOLDEN, "color_ref.npz"), allow_pickle=False)
+    venus = oracle.flo_read(os.path.join(GOLDEN, "gt_Venus_flow10.flo"))
+    cases = [(venus, -1.0, "venus_auto"), (venus, 3.5, "venus_max3p5"),
+             (ref["wheel_flow"], -1.0, "wheel_auto"), (ref["wheel_flow"], 40.0, "wheel_max40")]
+    for flow, maxmotion, key in cases:
+        got, rng = oracle.motion_to_color(flow, maxmotion, vendored=True)
+        assert np.array_equal(got, ref[key]), key
+        own, rng2 = oracle.motion_to_color(flow, maxmotion)
+        d = np.abs(own.astype(np.int16) - ref[key].astype(np.int16))
+        assert d.max() <= 1 and np.count_nonzero(d) <= 1e-4 * d.size, key
+        assert rng == rng2
+    # unknown pixels are black, the centre of the wheel (zero motion) is white
+    wheel = ref["wheel_auto"]
+    assert not wheel[5:9].any()
+    assert tuple(wheel[60, 90]) == (255, 255, 255)
+    # known answers on the axes of an all-in-range field: +u red-ish ... the wheel starts at red for angle pi
+    f = np.zeros((1, 4, 2), np.float32)
+    f[0, :, 0] = [1, -1, 0, 0]
+    f[0, :, 1] = [0, 0, 1, -1]
+    img, rng = oracle.motion_to_color(f)
+    assert rng == (1.0, -1.0, 1.0, -1.0, 1.0)
+    assert tuple(img[0, 0]) == (0, 0, 255)                     # B,G,R: pure red for motion to the right
+    zero, zr = oracle.motion_to_color(np.zeros((3, 3, 2), np.float32))
+    assert zr[0] == 0.0 and (zero == 255).all()                # maxrad 0 -> 1, every pixel white
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_GT), reason="reference data only exists in the build container")
+def test_colour_coding_of_all_gt_files_equals_reference(oracle, tmp_path):
+    stats = json.load(open(os.path.join(GOLDEN, "gt_stats.json")))
+    for seq, st in stats.items():
+        p = os.path.join(REF_GT, seq, "flow10.flo")
+        got, _ = oracle.motion_to_color(oracle.flo_read(p), vendored=True)
+        assert hashlib.sha256(got.tobytes()).hexdigest() == st["color_sha256"], seq
+        out = tmp_path / (seq + ".bgr")
+        subprocess.check_call([oracle.FLO_REF, "color", p, str(out)])
+        assert out.read_bytes() == got.tobytes()
+
+
 @pytest.mark.skipif(not os.path.isdir(REF_GT), reason="reference data only exists in the build container")
 def test_all_gt_files_roundtrip_through_reference_and_oracle(oracle, tmp_path):
     stats = json.load(open(os.path.join(GOLDEN, "gt_stats.json")))
