@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libbbme.so")
+LIB_PATH = os.environ.get("BBME_LIB") or os.path.join(_PKG, "libbbme.so")     # BBME_LIB: development builds
 MAX_LEVELS = 8
 
 OK, ERR_INVALID, ERR_PADDING, ERR_ODD_PADDING, ERR_DEGENERATE, ERR_HIP, ERR_IO, ERR_STATE, ERR_UNSUPPORTED = \

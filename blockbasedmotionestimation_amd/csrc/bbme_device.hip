@@ -55,7 +55,8 @@ struct bbme_ctx {
     std::vector<Level> lv;
     float *flow = nullptr;                        // dense padded H0 x W0 float2
     uint32_t *list[2] = {nullptr, nullptr};
-    uint32_t *own = nullptr;                      // ownership counters of the solver, 16 bits per block
+    uint32_t *own = nullptr;                      // ownership counters of the solver, one word per block
+    uint32_t own_pitch = 0;                       // transposed layout: 32 residue classes of own_pitch words
     uint32_t *counters = nullptr;                 // 8 words
     bool frames_set = false;
     int solve_wgs = 1280;                         // most workgroups of k_reg_solve (4 independent waves each)
@@ -172,7 +173,8 @@ void launch_sweep_t(const RegArgs &a, int max_solve_wgs, hipStream_t s)
     const long long blocks = (long long)a.rows * a.cols;
     const int grid1 = (int)((blocks * LPB + 255) / 256);
     // every solver wave scans 16 blocks per step; more workgroups than that would find nothing
-    const int grid2 = (int)std::min<long long>(max_solve_wgs, (blocks + 63) / 64);
+    // a multiple of 8 workgroups: one share per XCD (k_reg_solve's bands)
+    const int grid2 = (int)((std::min<long long>(max_solve_wgs, (blocks + 63) / 64) + 7) / 8 * 8);
     hipLaunchKernelGGL(k_reg_pass1<BS>, dim3(grid1), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_reg_solve<BS>, dim3(grid2), dim3(256), 0, s, a);
 }
@@ -202,6 +204,7 @@ int launch_sweep(bbme_ctx *c, int level, int b, int mult)
     a.lambda_mult = lambda * (float)mult;
     a.list0 = c->list[0]; a.list1 = c->list[1];
     a.own = c->own;
+    a.own_pitch = c->own_pitch;
     a.counters = c->counters;
     switch (b) {
     case 2:  launch_sweep_t<2>(a, c->solve_wgs, c->stream); break;
@@ -364,7 +367,9 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
                 return cleanup_fail(bbme::fail(BBME_ERR_HIP, "allocating search plan of level %d: %s", l, hipGetErrorString(err)));
         }
     }
-    const size_t bit_words = (max_blocks + 1) / 2 + 4;
+    // pitch = 33 (mod 64) words: consecutive blocks land 132 bytes (mod 256) apart
+    c->own_pitch = (uint32_t)(((max_blocks + 31) / 32 + 63) / 64 * 64 + 33);
+    const size_t bit_words = (size_t)c->own_pitch * 32;
     const size_t flow_bytes = (size_t)g.padded_width * g.padded_height * 2 * sizeof(float);
     if ((err = hipMalloc(&c->flow, flow_bytes)) != hipSuccess ||
         (err = hipMalloc(&c->list[0], max_blocks * 4)) != hipSuccess ||

@@ -400,7 +400,8 @@ struct RegArgs {
     float lambda_mult;          // lambda * (float)lambda_multiplier, computed as the reference does
     // work lists
     uint32_t *list0, *list1;    // block indices
-    uint32_t *own;              // ownership counters, 16 bits per block (see "work-list state" below)
+    uint32_t *own;              // ownership counters, one word per block (see "work-list state" below)
+    uint32_t own_pitch;         // words per residue class of the transposed layout (own_slot)
     uint32_t *counters;         // [0..2] list lengths (rotating), [3] safety-net passes, [4] blocks re-evaluated,
                                 // [5] sticky: a sweep hit a cap without converging, [6] solver ticket
 };
@@ -557,8 +558,35 @@ __device__ __forceinline__ mv_t eval_block(const RegArgs &a, int r, int c, int s
 // of 16 lanes and lane k < 9 owns candidate k: its address arithmetic, its image rows, its SAD, its
 // smoothness term (the other candidates arrive by shuffle) and its energy -- the same float expression
 // as in score_block, so the same winner: lowest energy, ties to the lowest k (:648-660).
+// DPP move within a row of 16 lanes (CTRL: quad_perm 0x00-0xff, row_mirror 0x140, row_half_mirror 0x141,
+// row_newbcast:n 0x150+n).  All 16 lanes of a row must be active.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_row(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true);
+}
+
+// Phase profile of a LANES round (development aid, compiled only with -DBBME_PHASE_PROFILE): shader-clock
+// stamps, each after every outstanding memory operation has returned, summed per phase in counters[9..15].
+#ifdef BBME_PHASE_PROFILE
+struct PhaseProf { uint32_t ph[7]; unsigned long long last; };
+__device__ __forceinline__ void phase_stamp(PhaseProf *p, int i)
+{
+    if (!p) return;
+    unsigned long long t;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    if (i >= 0) p->ph[i] += (uint32_t)(t - p->last);
+    p->last = t;
+}
+#define BBME_PHASE(p, i) phase_stamp(p, i)
+#else
+struct PhaseProf;
+#define BBME_PHASE(p, i) ((void)0)
+#endif
+
 template <int BS, bool COHERENT>
-__device__ __forceinline__ mv_t eval_block_lanes(const RegArgs &a, int r, int c, int k16, uint32_t use_new)
+__device__ __forceinline__ mv_t eval_block_lanes(const RegArgs &a, int r, int c, int k16, uint32_t use_new,
+                                                 PhaseProf *prof = nullptr)
 {
 #pragma clang fp contract(off)
     constexpr int NW = BS >= 4 ? BS / 4 : 1;
@@ -576,6 +604,7 @@ __device__ __forceinline__ mv_t eval_block_lanes(const RegArgs &a, int r, int c,
     const mv_t *src = ((use_new >> k) & 1u) ? a.est + (size_t)rs * a.cols + cs
                                             : a.old_grid + (size_t)(rs >> a.old_shift) * a.old_cols + (cs >> a.old_shift);
     const mv_t mv = load_est<COHERENT>(src);
+    BBME_PHASE(prof, 0);                                      // queue pop + address arithmetic + gather trip
     const int bx = c * BS, by = r * BS;
     int x2 = bx + mv_x(mv), y2 = by + mv_y(mv);
     const bool inside = present && !(x2 < 0 || x2 > a.width - BS || y2 < 0 || y2 > a.height - BS);   // :578
@@ -595,35 +624,44 @@ __device__ __forceinline__ mv_t eval_block_lanes(const RegArgs &a, int r, int c,
         }
     }
     const uint32_t sad = sad0 + sad1;
-    // smoothness: sum over the present candidates of |u_m - u_k| + |v_m - v_k| (:637-641)
+    BBME_PHASE(prof, 1);                                      // row loads + SAD
+    // smoothness: sum over the present candidates of |u_m - u_k| + |v_m - v_k| (:637-641).  The group is
+    // one DPP row of 16 lanes: candidate m reaches every lane by row_newbcast (a VALU move, no LDS trip)
     const int lane = (int)(threadIdx.x & 63u);
     const int base = lane & ~15;
     const uint32_t pmask = (uint32_t)(__ballot(present) >> base) & 0x1ffu;
     const uint32_t mine = mv ^ 0x80008000u;
     uint32_t smooth = 0;
-#pragma unroll
-    for (int m = 0; m < 9; ++m) {
-        const uint32_t other = (uint32_t)__shfl((int)mine, base + m);
-        if ((pmask >> m) & 1u) smooth = __builtin_amdgcn_sad_u16(other, mine, smooth);
-    }
+#define BBME_SMOOTH_TERM(m) \
+    { const uint32_t other = dpp_row<0x150 + (m)>(mine); if ((pmask >> (m)) & 1u) smooth = __builtin_amdgcn_sad_u16(other, mine, smooth); }
+    BBME_SMOOTH_TERM(0) BBME_SMOOTH_TERM(1) BBME_SMOOTH_TERM(2) BBME_SMOOTH_TERM(3) BBME_SMOOTH_TERM(4)
+    BBME_SMOOTH_TERM(5) BBME_SMOOTH_TERM(6) BBME_SMOOTH_TERM(7) BBME_SMOOTH_TERM(8)
+#undef BBME_SMOOTH_TERM
     float e = 3.402823466e+38f;                                                 // FLT_MAX :580
     if (inside) {
         const float t = a.lambda_mult * (float)smooth;
         e = (float)sad + t;                                                     // :607
     }
-    // energies are >= 0, so their bit patterns order like the floats; absent lanes sort last
+    // energies are >= 0, so their bit patterns order like the floats; absent lanes sort last.  The keys
+    // (energy, k) are distinct, so every lane of the row ends with the same winner whatever the order of
+    // the four exchanges: partner in the pair, in the quad, in the half row, in the row
     uint32_t ebits = present ? __float_as_uint(e) : 0xffffffffu;
     uint32_t who = (uint32_t)k16;
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-        const uint32_t oe = (uint32_t)__shfl_xor((int)ebits, o), ow = (uint32_t)__shfl_xor((int)who, o);
-        if (oe < ebits || (oe == ebits && ow < who)) { ebits = oe; who = ow; }
-    }
-    return (mv_t)__shfl((int)mv, base + (int)who);
+    mv_t winner = mv;
+#define BBME_ARGMIN_STEP(ctrl) \
+    { const uint32_t oe = dpp_row<ctrl>(ebits), ow = dpp_row<ctrl>(who), om = dpp_row<ctrl>(winner); \
+      if (oe < ebits || (oe == ebits && ow < who)) { ebits = oe; who = ow; winner = om; } }
+    BBME_ARGMIN_STEP(0xB1)      // quad_perm [1,0,3,2]
+    BBME_ARGMIN_STEP(0x4E)      // quad_perm [2,3,0,1]
+    BBME_ARGMIN_STEP(0x141)     // row_half_mirror
+    BBME_ARGMIN_STEP(0x140)     // row_mirror
+#undef BBME_ARGMIN_STEP
+    BBME_PHASE(prof, 2);                                      // smoothness + energy + argmin
+    return winner;
 }
 
 // ---- work-list state ---------------------------------------------------------------------
-// One 16-bit counter per block in `own` (two blocks per word), agent-scope atomics only:
+// One counter word per block in `own`, agent-scope atomics only:
 //   0      nobody is responsible for the block;
 //   >= 1   exactly one wave OWNS it: it sits in that wave's LDS queue (or on a global list) or is
 //          being evaluated by it.  Only the owner ever evaluates the block and stores its estimate;
@@ -632,18 +670,22 @@ __device__ __forceinline__ mv_t eval_block_lanes(const RegArgs &a, int r, int c,
 //        store has completed (and by the scan for blocks pass 1 left stale).  Old value 0: the
 //        caller becomes the owner and queues the block; its input loads come after this atomic,
 //        so they see every change made before it.  Old value > 0: the owner will redo it.
-// release after the owner's own store has completed: fetch_and(0).  Old value >= 2: claim again.
+// release after the owner's own store has completed: exchange with 0.  Old value >= 2: claim again.
 // Every change is followed by a claim on each dependant, every claimed block is evaluated with
 // inputs loaded after the claim, and no two waves evaluate one block at the same time; when every
 // queue is empty the field is the fixed point.
-__device__ __forceinline__ uint32_t own_shift(uint32_t x) { return 16u * (x & 1u); }
-__device__ __forceinline__ uint32_t own_claim(uint32_t *own, uint32_t x)      // returns the old counter
+// Layout: block x lives in word (x mod 32) * pitch + x / 32, pitch = 33 mod 64.  Neighbouring blocks
+// -- the ones a chain, or a cluster of stale blocks, claims at the same time -- are thus 132 bytes
+// (mod 256) apart: different cache lines on different L2 channels, instead of 32 atomics queueing
+// on one line.
+__device__ __forceinline__ uint32_t own_slot(const RegArgs &a, uint32_t x) { return (x & 31u) * a.own_pitch + (x >> 5); }
+__device__ __forceinline__ uint32_t own_claim(const RegArgs &a, uint32_t x)    // returns the old counter
 {
-    return (atomicAdd(&own[x >> 1], 1u << own_shift(x)) >> own_shift(x)) & 0xffffu;
+    return atomicAdd(&a.own[own_slot(a, x)], 1u);
 }
-__device__ __forceinline__ uint32_t own_release(uint32_t *own, uint32_t x)    // returns the old counter
+__device__ __forceinline__ uint32_t own_release(const RegArgs &a, uint32_t x)  // returns the old counter
 {
-    return (atomicAnd(&own[x >> 1], ~(0xffffu << own_shift(x))) >> own_shift(x)) & 0xffffu;
+    return atomicExch(&a.own[own_slot(a, x)], 0u);
 }
 #define BBME_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
@@ -653,6 +695,9 @@ __global__ __launch_bounds__(256) void k_reg_pass1(RegArgs a)
     constexpr int LPB = RegCfg<BS>::LPB;
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t == 0) { a.counters[0] = 0; a.counters[1] = 0; a.counters[2] = 0; a.counters[3] = 0; a.counters[4] = 0; a.counters[6] = 0; a.counters[7] = 0; a.counters[8] = 0; }
+#ifdef BBME_PHASE_PROFILE
+    if (t == 0) for (int i = 9; i < 16; ++i) a.counters[i] = 0;
+#endif
     const long long g = t / LPB;
     const int sub = (int)(t % LPB);
     if (g >= (long long)a.rows * a.cols) return;   // whole groups drop out together (LPB | 256)
@@ -707,7 +752,7 @@ __device__ __forceinline__ void drain_lists(const RegArgs &a, int t, int nthread
         for (uint32_t idx = group; idx < n; idx += ngroups) {
             const uint32_t x = __hip_atomic_load(&lcur[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int r = (int)(x / a.cols), c = (int)(x % a.cols);
-            if (sub == 0) own_release(a.own, x);                                  // the list owned it
+            if (sub == 0) own_release(a, x);                                  // the list owned it
             BBME_DRAIN();
             const mv_t res = eval_block_lanes<BS, true>(a, r, c, sub, BBME_NEW_MASK);
             if (sub == 0 && res != load_est<true>(a.est + x)) {
@@ -719,7 +764,7 @@ __device__ __forceinline__ void drain_lists(const RegArgs &a, int t, int nthread
                     const int rr = r + dr[d], cc = c + dc[d];
                     if (rr >= a.rows || cc < 0 || cc >= a.cols) continue;
                     const uint32_t xd = (uint32_t)rr * a.cols + cc;
-                    if (own_claim(a.own, xd) == 0)
+                    if (own_claim(a, xd) == 0)
                         __hip_atomic_store(&lnext[atomicAdd(cnext, 1u)], xd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
@@ -753,12 +798,26 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint32_t *q = qmem[wave];
-    const uint32_t w = blockIdx.x * 4 + wave, W = gridDim.x * 4;
     const uint32_t nblocks = (uint32_t)a.rows * a.cols;
+    // Workgroups go round-robin to the 8 XCDs, each with its own L2.  XCD j scans the j-th band of
+    // the raster, and a wave follows its own chains, so the estimates and ownership words of a band
+    // are read, written and claimed through ONE L2 instead of bouncing between eight of them (the
+    // launch has a multiple of 8 workgroups; bands are whole scan chunks).
+    constexpr uint32_t SCAN = 16;
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t w = (blockIdx.x >> 3) * 4 + wave, W = (gridDim.x >> 3) * 4;
+    const uint32_t band = ((nblocks + 8 * SCAN - 1) / (8 * SCAN)) * SCAN;
+    const uint32_t band_begin = min(xcd * band, nblocks), band_end = min(band_begin + band, nblocks);
     uint32_t *ovf_list = a.list0;
     uint32_t *ovf_count = &a.counters[1];
     uint32_t head = 0, tail = 0;                  // wave-uniform, free-running
     uint32_t evaluated = 0, rounds = 0;
+#ifdef BBME_PHASE_PROFILE
+    PhaseProf prof_s = {};
+    PhaseProf *prof = nullptr;
+#else
+    PhaseProf *prof = nullptr;
+#endif
     // every round either empties part of the queue or follows a real change; the cap is only an
     // exit that every wave reaches should that reasoning ever be wrong (reported via counters[5])
     const uint32_t round_cap = 64u * (uint32_t)(2 * a.rows + a.cols + 16);
@@ -779,13 +838,12 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
 
     // scan granularity: two rounds' worth of blocks, so that a cluster of stale blocks is spread
     // over many waves instead of queueing up behind one
-    constexpr uint32_t SCAN = 16;
-    for (uint32_t base = w * SCAN;; base += W * SCAN) {
-        if (base < nblocks) {
+    for (uint32_t base = band_begin + w * SCAN;; base += W * SCAN) {
+        if (base < band_end) {
             const uint32_t x = base + lane;
             bool mine = false;
-            if ((uint32_t)lane < SCAN && x < nblocks && block_is_stale(a, (int)(x / a.cols), (int)(x % a.cols)))
-                mine = own_claim(a.own, x) == 0;
+            if ((uint32_t)lane < SCAN && x < band_end && block_is_stale(a, (int)(x / a.cols), (int)(x % a.cols)))
+                mine = own_claim(a, x) == 0;
             enqueue(mine, x);
         } else if (head == tail) {
             break;
@@ -793,6 +851,11 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
         while (head != tail) {
             if (++rounds > round_cap) { if (lane == 0) a.counters[5] = 1; head = tail; break; }
             const bool wide = NBW > NBL && tail - head > (uint32_t)NBL;   // wave-uniform
+#ifdef BBME_PHASE_PROFILE
+            prof = wide ? nullptr : &prof_s;
+            if (prof) prof_s.ph[6]++;
+            BBME_PHASE(prof, -1);
+#endif
             const int gl = wide ? LPBW : 16;                             // lanes per block this round
             const int g = lane / gl, sub = lane % gl;
             const uint32_t cnt = min((uint32_t)(wide ? NBW : NBL), tail - head);
@@ -808,12 +871,13 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
                 if (leader) prev = load_est<true>(a.est + x);          // issued with the candidate loads
                 mv_t res;
                 if (wide) res = eval_block<BS, true>(a, r, c, sub, BBME_NEW_MASK);
-                else res = eval_block_lanes<BS, true>(a, r, c, sub, BBME_NEW_MASK);
+                else res = eval_block_lanes<BS, true>(a, r, c, sub, BBME_NEW_MASK, prof);
                 changed = leader && res != prev;
                 if (changed) __hip_atomic_store(a.est + x, res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             evaluated += cnt;
             if (__ballot(changed)) BBME_DRAIN();                       // the stores have completed
+            BBME_PHASE(prof, 3);                                        // store + drain
             // one trip for all five atomics: claim the dependants R, DR, D, DL and release x
             const int dr[4] = {0, 1, 1, 1}, dc[4] = {1, 1, 0, -1};
             uint32_t xd[4], was[4];
@@ -824,19 +888,49 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
                 want[d] = changed && rr < a.rows && cc >= 0 && cc < a.cols;
                 xd[d] = want[d] ? (uint32_t)rr * a.cols + cc : 0u;
                 was[d] = 1;
-                if (want[d]) was[d] = own_claim(a.own, xd[d]);
+                if (want[d]) was[d] = own_claim(a, xd[d]);
             }
             uint32_t wasx = 0;
-            if (leader) wasx = own_release(a.own, x);
+            if (leader) wasx = own_release(a, x);
+            BBME_PHASE(prof, 4);                                        // claim dependants + release
+            // the newly owned dependants go on the queue: the four ballots first, then the stores, so
+            // that the round does not wait on four enqueues in a row
+            {
+                unsigned long long m[4];
+                uint32_t tot[4], total = 0;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) enqueue(want[d] && was[d] == 0, xd[d]);
+                for (int d = 0; d < 4; ++d) {
+                    m[d] = __ballot(want[d] && was[d] == 0);
+                    tot[d] = (uint32_t)__popcll(m[d]);
+                    total += tot[d];
+                }
+                if (total != 0 && tail - head + total <= QCAP) {
+                    uint32_t off = tail;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        if (want[d] && was[d] == 0) q[(off + (uint32_t)__popcll(m[d] & lt_mask)) % QCAP] = xd[d];
+                        off += tot[d];
+                    }
+                    tail = __builtin_amdgcn_readfirstlane(tail + total);
+                } else if (total != 0) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) enqueue(want[d] && was[d] == 0, xd[d]);
+                }
+            }
             // an input changed while we held x: take it again (unless somebody else just did)
-            bool again = false;
-            if (leader && wasx >= 2) again = own_claim(a.own, x) == 0;
-            enqueue(again, x);
-            if (wasx >= 0x8000u) a.counters[5] = 1;                    // counter close to overflow: report
+            if (__ballot(leader && wasx >= 2)) {
+                bool again = false;
+                if (leader && wasx >= 2) again = own_claim(a, x) == 0;
+                enqueue(again, x);
+            }
+            if (wasx >= 0x80000000u) a.counters[5] = 1;                // counter close to overflow: report
+            BBME_PHASE(prof, 5);                                        // enqueue + re-claim
         }
     }
+#ifdef BBME_PHASE_PROFILE
+    if (lane == 0 && prof_s.ph[6])
+        for (int i = 0; i < 7; ++i) atomicAdd(&a.counters[9 + i], prof_s.ph[i]);
+#endif
     if (lane == 0 && evaluated) { atomicAdd(&a.counters[4], evaluated); atomicMax(&a.counters[7], rounds); atomicAdd(&a.counters[8], rounds); }
 
     // epilogue: the workgroup that takes the last ticket knows every other one has finished (their
