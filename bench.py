@@ -280,6 +280,22 @@ def main():
                                                      "x 16 abs-diff per lane (v_sad_u8: %.1f T/s)" % sad_peak}},
             "device_ms": {k: round(val, 4) for k, val in prof.items()},
         }
+        # the regulariser takes most of the step although it is 2 % of the arithmetic: every sweep is a
+        # chain of dependent block updates.  Algorithmic bytes of a sweep at block size b: per b x b block
+        # its own pixels, nine candidate blocks (10 b^2) and nine MVs in, one out (40).
+        reg_bytes = 0
+        for l in range(levels):
+            b = block
+            while b > 1:
+                reg_bytes += 2 * ((pw >> l) // b) * ((ph >> l) // b) * (10 * b * b + 40)
+                b >>= 1
+        reg_gbs = reg_bytes / (prof["regularize_ms"] * 1e-3) / 1e9
+        out["regularizer"] = {"bound": "latency (dependent block updates; neither HBM nor VALU)",
+                              "kernels": "k_reg_pass1<b> + k_reg_solve<b>, %d sweeps per pyramid" % (2 * levels * (block.bit_length() - 1)),
+                              "ms": round(prof["regularize_ms"], 4),
+                              "share_of_step": round(prof["regularize_ms"] / prof["total_ms"], 3),
+                              "algorithmic_bytes": reg_bytes, "achieved": round(reg_gbs, 2), "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": round(reg_gbs / HBM_PEAK_GBS, 5)}
         if sequence is not None:
             out["sequence"] = sequence
         out["epe_vs_middlebury_gt"] = epe_on_ground_truth(bbme, local_rank)

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): everything profiles/ is made from, into gpurun_out/refresh/.
+#   bash scripts/refresh_profiles.sh
+# Afterwards, locally: scripts/pmc_report.py on the two pmc directories, copy the stats csv and the bench line.
+REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$REPO/gpurun_out/refresh
+rm -rf $OUT && mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 python3 $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
+echo "bench done"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py --no-cpu-baseline --in-flight 0 > $OUT/stats.log 2>&1 || exit 1
+echo "stats done"
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/scripts/pmc_workload.py > $OUT/pmc_fetch.log 2>&1 || exit 1
+echo "pmc fetch done"
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $REPO/scripts/pmc_workload.py > $OUT/pmc_write.log 2>&1 || exit 1
+echo "pmc write done"
+find $OUT -name "*kernel_trace.csv" -size +20M -delete
