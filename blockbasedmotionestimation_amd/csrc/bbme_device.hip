@@ -55,6 +55,8 @@ struct bbme_ctx {
     std::vector<Level> lv;
     float *flow = nullptr;                        // dense padded H0 x W0 float2
     uint32_t *list[2] = {nullptr, nullptr};
+    uint8_t *flags[2] = {nullptr, nullptr};       // dirty flags of the regulariser, one byte per block, all zero between sweeps
+    int relax_steps = -1;                         // k_reg_iter launches per sweep; -1 = by size (BBME_RELAX_STEPS overrides)
     uint32_t *own = nullptr;                      // ownership counters of the solver, one word per block
     uint32_t own_pitch = 0;                       // transposed layout: 32 residue classes of own_pitch words
     uint32_t *counters = nullptr;                 // 8 words
@@ -167,7 +169,7 @@ int launch_search(bbme_ctx *c, int level)
 }
 
 template <int BS>
-void launch_sweep_t(const RegArgs &a, int max_solve_wgs, hipStream_t s)
+void launch_sweep_t(RegArgs a, uint8_t *const flags[2], int relax_steps, int max_solve_wgs, hipStream_t s)
 {
     constexpr int LPB = RegCfg<BS>::LPB;
     const long long blocks = (long long)a.rows * a.cols;
@@ -175,11 +177,20 @@ void launch_sweep_t(const RegArgs &a, int max_solve_wgs, hipStream_t s)
     // every solver wave scans 16 blocks per step; more workgroups than that would find nothing
     // a multiple of 8 workgroups: one share per XCD (k_reg_solve's bands)
     const int grid2 = (int)((std::min<long long>(max_solve_wgs, (blocks + 63) / 64) + 7) / 8 * 8);
+    // pass 1 marks flags[0]; relaxation step i consumes flags[i & 1] and marks the other; the solver
+    // consumes what the last step marked.  Every flag is zero again afterwards.
+    a.flag_cur = nullptr; a.flag_next = flags[0];
     hipLaunchKernelGGL(k_reg_pass1<BS>, dim3(grid1), dim3(256), 0, s, a);
+    int cur = 0;
+    for (int i = 0; i < relax_steps; ++i, cur ^= 1) {
+        a.flag_cur = flags[cur]; a.flag_next = flags[cur ^ 1];
+        hipLaunchKernelGGL(k_reg_iter<BS>, dim3((unsigned)((blocks + RegIter<BS>::PER_WG - 1) / RegIter<BS>::PER_WG)),
+                           dim3(256), 0, s, a);
+    }
+    a.flag_cur = flags[cur]; a.flag_next = nullptr;
     hipLaunchKernelGGL(k_reg_solve<BS>, dim3(grid2), dim3(256), 0, s, a);
 }
 
-// One regularize_MVs() sweep at block size b (divide_blocks fused when the grid is at 2b).
 int launch_sweep(bbme_ctx *c, int level, int b, int mult)
 {
     Level &L = c->lv[level];
@@ -206,13 +217,19 @@ int launch_sweep(bbme_ctx *c, int level, int b, int mult)
     a.own = c->own;
     a.own_pitch = c->own_pitch;
     a.counters = c->counters;
+    // relaxation steps: a step is one more launch (>= 5 us), which only the sweeps with heavy first generations
+    // repay -- measured on cfg3 (scripts/trace_table.py): large grids of small blocks, two steps for the first sweep
+    // of a block size (lambda has just doubled), one for the second
+    const long long nblk = (long long)a.rows * a.cols;
+    int steps = c->relax_steps;
+    if (steps < 0) steps = (nblk >= 100000 && b <= 4) ? (mult == 1 ? 2 : 1) : 0;
     switch (b) {
-    case 2:  launch_sweep_t<2>(a, c->solve_wgs, c->stream); break;
-    case 4:  launch_sweep_t<4>(a, c->solve_wgs, c->stream); break;
-    case 8:  launch_sweep_t<8>(a, c->solve_wgs, c->stream); break;
-    case 16: launch_sweep_t<16>(a, c->solve_wgs, c->stream); break;
-    case 32: launch_sweep_t<32>(a, c->solve_wgs, c->stream); break;
-    case 64: launch_sweep_t<64>(a, c->solve_wgs, c->stream); break;
+    case 2:  launch_sweep_t<2>(a, c->flags, steps, c->solve_wgs, c->stream); break;
+    case 4:  launch_sweep_t<4>(a, c->flags, steps, c->solve_wgs, c->stream); break;
+    case 8:  launch_sweep_t<8>(a, c->flags, steps, c->solve_wgs, c->stream); break;
+    case 16: launch_sweep_t<16>(a, c->flags, steps, c->solve_wgs, c->stream); break;
+    case 32: launch_sweep_t<32>(a, c->flags, steps, c->solve_wgs, c->stream); break;
+    case 64: launch_sweep_t<64>(a, c->flags, steps, c->solve_wgs, c->stream); break;
     default: return bbme::fail(BBME_ERR_UNSUPPORTED, "block size %d", b);
     }
     HIP_TRY(hipGetLastError());
@@ -319,6 +336,7 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
     bbme_ctx *c = new bbme_ctx();
     c->params = *params; c->geom = g; c->device = device;
     if (const char *e = getenv("BBME_SOLVE_WGS")) c->solve_wgs = std::max(1, std::min(8192, atoi(e)));
+    if (const char *e = getenv("BBME_RELAX_STEPS")) c->relax_steps = std::max(0, std::min(64, atoi(e)));
     if (const char *e = getenv("BBME_NO_GRAPH")) c->use_graph = atoi(e) == 0;
     if (const char *e = getenv("BBME_GENERIC_SEARCH")) c->force_generic_search = atoi(e) != 0;
     if (const char *e = getenv("BBME_XCD_REMAP")) c->xcd_remap = atoi(e) != 0;
@@ -371,10 +389,15 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
     c->own_pitch = (uint32_t)(((max_blocks + 31) / 32 + 63) / 64 * 64 + 33);
     const size_t bit_words = (size_t)c->own_pitch * 32;
     const size_t flow_bytes = (size_t)g.padded_width * g.padded_height * 2 * sizeof(float);
+    const size_t flag_bytes = (max_blocks + 2047) / 2048 * 2048 + 2048;       // k_reg_iter reads whole 2048-block chunks
     if ((err = hipMalloc(&c->flow, flow_bytes)) != hipSuccess ||
         (err = hipMalloc(&c->list[0], max_blocks * 4)) != hipSuccess ||
         (err = hipMalloc(&c->list[1], max_blocks * 4)) != hipSuccess ||
         (err = hipMalloc(&c->own, bit_words * 4)) != hipSuccess ||
+        (err = hipMalloc(&c->flags[0], flag_bytes)) != hipSuccess ||
+        (err = hipMalloc(&c->flags[1], flag_bytes)) != hipSuccess ||
+        (err = hipMemset(c->flags[0], 0, flag_bytes)) != hipSuccess ||
+        (err = hipMemset(c->flags[1], 0, flag_bytes)) != hipSuccess ||
         (err = hipMalloc(&c->counters, 64)) != hipSuccess ||
         (err = hipMemset(c->own, 0, bit_words * 4)) != hipSuccess ||
         (err = hipMemset(c->counters, 0, 64)) != hipSuccess ||
@@ -400,6 +423,7 @@ int bbme_destroy(bbme_ctx *c)
     (void)hipFree(c->flow);
     (void)hipFree(c->list[0]); (void)hipFree(c->list[1]);
     (void)hipFree(c->own);
+    (void)hipFree(c->flags[0]); (void)hipFree(c->flags[1]);
     (void)hipFree(c->counters);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -380,11 +380,13 @@ __global__ __launch_bounds__(64) void k_search_fast(FastSearchArgs a)
 // sees the already-updated values of its left / upper neighbours and the old values of itself
 // and its right / lower neighbours.  The dependency graph of `new` is acyclic, so the field
 // is the unique fixed point of that system.  We reach it by:
-//   pass 1   every block evaluated with new := old                          (k_reg_pass1)
-//   solve    every block whose L/UL/U/UR changed in pass 1 is queued and re-evaluated; a block
-//            that changes claims R, DR, D, DL (its dependants) -- asynchronously, each wave
-//            following its own chains                                       (k_reg_solve)
-// until no block is queued.  Two launches per sweep, no host synchronisation.  Energies are float32 exactly as the reference's
+//   pass 1   every block evaluated with new := old; a block that comes out different from its old
+//            value marks its dependants R, DR, D, DL in a byte map         (k_reg_pass1)
+//   relax    (0-2 launches, large grids only) the marked blocks re-evaluated in place, chip-wide,
+//            plain loads and stores; changes mark dependants again          (k_reg_iter)
+//   solve    the marked blocks are queued and re-evaluated; a block that changes claims its
+//            dependants -- asynchronously, each wave following its own chains (k_reg_solve)
+// until no block is queued.  Two to four launches per sweep, no host synchronisation.  Energies are float32 exactly as the reference's
 // (SAD + lambda * mult * Smoothness, FLT_MAX for out-of-image candidates, first strict min).
 //
 // BS x BS blocks; LPB lanes cooperate on one block, one image row per lane.
@@ -402,6 +404,9 @@ struct RegArgs {
     uint32_t *list0, *list1;    // block indices
     uint32_t *own;              // ownership counters, one word per block (see "work-list state" below)
     uint32_t own_pitch;         // words per residue class of the transposed layout (own_slot)
+    // dirty flags, one byte per block: a kernel consumes (and zeroes) flag_cur and marks flag_next.  A block is
+    // marked when one of its already-updated inputs (L, UL, UR, U) has just been changed.
+    uint8_t *flag_cur, *flag_next;
     uint32_t *counters;         // [0..2] list lengths (rotating), [3] safety-net passes, [4] blocks re-evaluated,
                                 // [5] sticky: a sweep hit a cap without converging, [6] solver ticket
 };
@@ -689,6 +694,17 @@ __device__ __forceinline__ uint32_t own_release(const RegArgs &a, uint32_t x)  /
 }
 #define BBME_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
+// block (r, c) has a new estimate: its dependants R, DR, D, DL must be looked at again (idempotent byte stores)
+__device__ __forceinline__ void mark_dependants(const RegArgs &a, uint8_t *flags, int r, int c)
+{
+    const int dr[4] = {0, 1, 1, 1}, dc[4] = {1, 1, 0, -1};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int rr = r + dr[d], cc = c + dc[d];
+        if (rr < a.rows && cc >= 0 && cc < a.cols) flags[(size_t)rr * a.cols + cc] = 1;
+    }
+}
+
 template <int BS>
 __global__ __launch_bounds__(256) void k_reg_pass1(RegArgs a)
 {
@@ -703,25 +719,60 @@ __global__ __launch_bounds__(256) void k_reg_pass1(RegArgs a)
     if (g >= (long long)a.rows * a.cols) return;   // whole groups drop out together (LPB | 256)
     const int r = (int)(g / a.cols), c = (int)(g % a.cols);
     const mv_t res = eval_block<BS, false, true>(a, r, c, sub, 0u);
-    if (sub == 0) a.est[g] = res;
+    if (sub == 0) {
+        a.est[g] = res;
+        // the blocks that read this one as an already-updated input assumed the old value
+        const mv_t old = a.old_grid[(size_t)(r >> a.old_shift) * a.old_cols + (c >> a.old_shift)];
+        if (res != old) mark_dependants(a, a.flag_next, r, c);
+    }
 }
 
-// Is block (r, c) stale after pass 1?  Pull form: it must be re-evaluated iff one of its
-// already-updated inputs (L, UL, U, UR) came out of pass 1 different from the old value that
-// pass 1 assumed for it.
-__device__ __forceinline__ bool block_is_stale(const RegArgs &a, int r, int c)
+// One relaxation step over the marked blocks, the whole chip at once, plain loads and stores: every
+// block marked in flag_cur is evaluated in place with the estimates as they are (an input that is being
+// rewritten in this very launch may be seen old or new -- if old, its writer marks this block again); a
+// block that changes marks its dependants in flag_next.  Asynchronous fixed-point iteration: any number
+// of these steps, followed by k_reg_solve, ends at the same (unique) field.  A step costs one launch; it
+// pays for itself on the first generations of a heavy sweep, where thousands of blocks are stale at once
+// and the solver's coherent traffic and memory-side atomics queue up.
+// a workgroup evaluates 256 / LPB blocks at a time; it scans four times that many, so that with up to a
+// quarter of the blocks marked it needs one round
+template <int BS> struct RegIter {
+    static constexpr int PER_WG = 4 * 256 / RegCfg<BS>::LPB < 64 ? 64 : 4 * 256 / RegCfg<BS>::LPB;
+};
+template <int BS>
+__global__ __launch_bounds__(256) void k_reg_iter(RegArgs a)
 {
-    bool stale = false;
+    constexpr int LPB = RegCfg<BS>::LPB;
+    constexpr int PER_WG = RegIter<BS>::PER_WG;               // blocks scanned by a workgroup
+    __shared__ uint32_t list[PER_WG];
+    __shared__ uint32_t n_marked;
+    if (threadIdx.x == 0) n_marked = 0;
+    __syncthreads();
+    const uint32_t nblocks = (uint32_t)a.rows * a.cols;
+    const uint32_t base = blockIdx.x * PER_WG;
+    uint32_t *words = reinterpret_cast<uint32_t *>(a.flag_cur);   // padded to a multiple of PER_WG bytes
+    for (int j = threadIdx.x; j < PER_WG / 4; j += 256) {
+        const uint32_t wi = base / 4 + j;
+        const uint32_t f = words[wi];
+        if (f) {
+            words[wi] = 0;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        if (!((BBME_NEW_MASK >> k) & 1u)) continue;
-        const int rr = r + kNbRow[k], cc = c + kNbCol[k];
-        if (rr < 0 || rr >= a.rows || cc < 0 || cc >= a.cols) continue;
-        const mv_t e = a.est[(size_t)rr * a.cols + cc];                       // as pass 1 wrote it
-        const mv_t o = a.old_grid[(size_t)(rr >> a.old_shift) * a.old_cols + (cc >> a.old_shift)];
-        stale |= (e != o);
+            for (int k = 0; k < 4; ++k)
+                if (((f >> (8 * k)) & 0xffu) && wi * 4 + k < nblocks) list[atomicAdd(&n_marked, 1u)] = wi * 4 + k;
+        }
     }
-    return stale;
+    __syncthreads();
+    const uint32_t cnt = n_marked;
+    const int sub = threadIdx.x % LPB;
+    for (uint32_t idx = threadIdx.x / LPB; idx < cnt; idx += 256 / LPB) {
+        const uint32_t x = list[idx];
+        const int r = (int)(x / a.cols), c = (int)(x % a.cols);
+        const mv_t res = eval_block<BS, false>(a, r, c, sub, BBME_NEW_MASK);
+        if (sub == 0 && res != a.est[x]) {
+            a.est[x] = res;
+            mark_dependants(a, a.flag_next, r, c);
+        }
+    }
 }
 
 // One work-list pass of the safety net (see k_reg_solve's epilogue): `nthreads` threads of one
@@ -776,8 +827,9 @@ __device__ __forceinline__ void drain_lists(const RegArgs &a, int t, int nthread
     }
 }
 
-// Asynchronous solver.  Every wave owns a private LDS queue.  It scans its share of the grid for
-// blocks that pass 1 left stale (16 blocks at a time), queues them, and whatever its own changes
+// Asynchronous solver.  Every wave owns a private LDS queue.  It scans its share of the dirty flags
+// (blocks one of whose already-updated inputs was changed by pass 1 or by the last relaxation step; 16
+// at a time), queues the marked blocks, and whatever its own changes
 // make stale it queues locally too and evaluates itself, round after round, without any grid-wide
 // step: fixed-point iteration tolerates any evaluation order.  A wave whose queue is empty and
 // which has scanned its share simply exits.  If a local queue is full the surplus goes to a
@@ -842,8 +894,10 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
         if (base < band_end) {
             const uint32_t x = base + lane;
             bool mine = false;
-            if ((uint32_t)lane < SCAN && x < band_end && block_is_stale(a, (int)(x / a.cols), (int)(x % a.cols)))
+            if ((uint32_t)lane < SCAN && x < band_end && a.flag_cur[x]) {
+                a.flag_cur[x] = 0;
                 mine = own_claim(a, x) == 0;
+            }
             enqueue(mine, x);
         } else if (head == tail) {
             break;
