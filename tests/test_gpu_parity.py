@@ -127,6 +127,20 @@ def test_random_configurations_twice(bbme, oracle, seed):
     mf.close()
     assert np.array_equal(a, exp), "first run differs from the oracle: %s %s %s" % (f1.shape, search, blocks)
     assert np.array_equal(b, exp), "second run differs from the oracle"
+    # the chip-wide relaxation steps before the solver (by default only on grids of >= 100 000 blocks) forced on:
+    # any number of them must leave the result untouched
+    import os
+    for steps in ("1", "3"):
+        os.environ["BBME_RELAX_STEPS"] = steps
+        try:
+            mf = bbme.MF(f1, f2, search, blocks, L)
+        finally:
+            del os.environ["BBME_RELAX_STEPS"]
+        for lvl in range(L):
+            mf.set_level_planes(lvl, omf.image(lvl, 1), omf.image(lvl, 2))
+        c = mf.calcMotionBlockMatching()
+        mf.close()
+        assert np.array_equal(c, exp), "%s relaxation steps per sweep change the field" % steps
 
 
 def test_flat_and_zero_frames_tie_breaking(bbme, oracle):
@@ -158,6 +172,18 @@ def test_large_motion_predictions_leave_image(bbme, oracle):
     f1 = rng.integers(0, 256, (256, 320), dtype=np.uint8)
     f2 = np.roll(f1, (37, -45), axis=(0, 1))
     compare_stagewise(bbme, oracle, f1, f2, [80, 80, 80], [16, 16, 16])
+
+
+def test_stagewise_parity_with_relaxation_steps(bbme, oracle, monkeypatch):
+    """Every intermediate MV grid with two relaxation steps forced into every sweep (k_reg_iter), on content
+    with many changes per sweep."""
+    monkeypatch.setenv("BBME_RELAX_STEPS", "2")
+    f1, f2, _ = bbme.synth_pair(328, 200, 5151, max_motion=12)
+    compare_stagewise(bbme, oracle, f1, f2, [48, 48, 48], [16, 16, 16])
+    rng = np.random.default_rng(12)
+    n1 = rng.integers(0, 256, (160, 224), dtype=np.uint8)
+    n2 = rng.integers(0, 256, (160, 224), dtype=np.uint8)
+    compare_stagewise(bbme, oracle, n1, n2, [40, 40], [8, 8])
 
 
 def test_noise_frames(bbme, oracle):
@@ -304,6 +330,21 @@ def test_errors_through_the_boundary(bbme):
         mf.stage_regularize(1, 4, 1)
     assert e.value.status == -7
     mf.close()
+
+
+def test_1080p_pair_against_oracle(bbme, oracle):
+    """BASELINE configs[1] at full size (1920x1080, 16x16, +-16, 3 levels) against the oracle, a few seconds of CPU:
+    large enough (130 560 / 522 240 blocks at b = 4 / 2) for the default schedule to include relaxation steps."""
+    f1, f2, _ = bbme.synth_pair(1920, 1080, 1020, max_motion=12)
+    search, block = [48] * 3, [16] * 3
+    omf = oracle.OracleMF(f1, f2, search, block, use_cache=False)
+    exp = omf.calc_motion_block_matching()
+    mf = bbme.MF(f1, f2, search, block, 3)
+    got = mf.calcMotionBlockMatching()
+    again = mf.calcMotionBlockMatching()
+    mf.close()
+    omf.close()
+    assert np.array_equal(got, exp) and np.array_equal(again, exp)
 
 
 def test_pipelined_sequence_matches_oracle_per_pair(bbme, oracle):
