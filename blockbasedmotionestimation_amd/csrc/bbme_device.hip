@@ -61,7 +61,7 @@ struct bbme_ctx {
     uint32_t own_pitch = 0;                       // transposed layout: 32 residue classes of own_pitch words
     uint32_t *counters = nullptr;                 // 8 words
     bool frames_set = false;
-    int solve_wgs = 1280;                         // most workgroups of k_reg_solve (4 independent waves each)
+    int solve_wgs = 256;                          // most workgroups of k_reg_solve (4 independent waves each): one wave per SIMD
     int xcd_remap = 1;                            // XCD-aware block order in k_search_fast; BBME_XCD_REMAP
     bool force_generic_search = false;            // BBME_GENERIC_SEARCH=1: use k_search_generic everywhere
     bool use_graph = true;
@@ -216,13 +216,25 @@ int launch_sweep(bbme_ctx *c, int level, int b, int mult)
     a.list0 = c->list[0]; a.list1 = c->list[1];
     a.own = c->own;
     a.own_pitch = c->own_pitch;
+    static const int wide_env = getenv("BBME_WIDE_THRESHOLD") ? atoi(getenv("BBME_WIDE_THRESHOLD")) : 4;
+    a.wide_threshold = (uint32_t)std::max(4, wide_env);
     a.counters = c->counters;
     // relaxation steps: a step is one more launch (>= 5 us), which only the sweeps with heavy first generations
-    // repay -- measured on cfg3 (scripts/trace_table.py): large grids of small blocks, two steps for the first sweep
-    // of a block size (lambda has just doubled), one for the second
+    // repay -- measured on cfg3 / cfg4 (scripts/trace_table.py): large grids of small blocks, four steps for the first
+    // sweep of a block size (lambda has just doubled), two for the second
     const long long nblk = (long long)a.rows * a.cols;
     int steps = c->relax_steps;
-    if (steps < 0) steps = (nblk >= 100000 && b <= 4) ? (mult == 1 ? 2 : 1) : 0;
+    if (steps < 0) {
+        // BBME_RELAX_RULE="min_blocks,max_b,steps_first,steps_second" (tuning knob)
+        static long long min_blocks = 100000;
+        static int max_b = 4, s1 = 4, s2 = 2;
+        static const bool parsed = [] {
+            if (const char *e = getenv("BBME_RELAX_RULE")) sscanf(e, "%lld,%d,%d,%d", &min_blocks, &max_b, &s1, &s2);
+            return true;
+        }();
+        (void)parsed;
+        steps = (nblk >= min_blocks && b <= max_b) ? (mult == 1 ? s1 : s2) : 0;
+    }
     switch (b) {
     case 2:  launch_sweep_t<2>(a, c->flags, steps, c->solve_wgs, c->stream); break;
     case 4:  launch_sweep_t<4>(a, c->flags, steps, c->solve_wgs, c->stream); break;

@@ -407,6 +407,7 @@ struct RegArgs {
     // dirty flags, one byte per block: a kernel consumes (and zeroes) flag_cur and marks flag_next.  A block is
     // marked when one of its already-updated inputs (L, UL, UR, U) has just been changed.
     uint8_t *flag_cur, *flag_next;
+    uint32_t wide_threshold;    // solver: queue length above which a round uses the throughput form
     uint32_t *counters;         // [0..2] list lengths (rotating), [3] safety-net passes, [4] blocks re-evaluated,
                                 // [5] sticky: a sweep hit a cap without converging, [6] solver ticket
 };
@@ -904,7 +905,7 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
         }
         while (head != tail) {
             if (++rounds > round_cap) { if (lane == 0) a.counters[5] = 1; head = tail; break; }
-            const bool wide = NBW > NBL && tail - head > (uint32_t)NBL;   // wave-uniform
+            const bool wide = NBW > NBL && tail - head > a.wide_threshold;   // wave-uniform
 #ifdef BBME_PHASE_PROFILE
             prof = wide ? nullptr : &prof_s;
             if (prof) prof_s.ph[6]++;
