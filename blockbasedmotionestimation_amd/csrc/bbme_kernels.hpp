@@ -555,6 +555,13 @@ __device__ __forceinline__ mv_t eval_block(const RegArgs &a, int r, int c, int s
         else
             cand[k] = a.old_grid[(size_t)(rs >> a.old_shift) * a.old_cols + (cs >> a.old_shift)];
     }
+    // All candidates equal (the common case inside a moving region): they have the same SAD and the same smoothness
+    // (or all lie outside the image: FLT_MAX), so the first one -- the block's own old MV -- stays (:648-660).
+    // No image row is touched; whole waves leave here where the field is locally constant.
+    bool uniform = true;
+#pragma unroll
+    for (int k = 1; k < 9; ++k) uniform &= !((present >> k) & 1u) || cand[k] == cand[0];
+    if (uniform) return cand[0];
     return score_block<BS, DEDUP>(a, cand, present, c * BS, r * BS, sub);
 }
 
