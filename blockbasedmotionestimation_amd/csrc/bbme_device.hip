@@ -56,7 +56,7 @@ struct bbme_ctx {
     float *flow = nullptr;                        // dense padded H0 x W0 float2
     uint32_t *list[2] = {nullptr, nullptr};
     uint8_t *flags[2] = {nullptr, nullptr};       // dirty flags of the regulariser, one byte per block, all zero between sweeps
-    int relax_steps = -1;                         // k_reg_iter launches per sweep; -1 = by size (BBME_RELAX_STEPS overrides)
+    int relax_steps = -1;                         // k_reg_iter launches per sweep; -1 = by grid size (BBME_RELAX_STEPS overrides)
     uint32_t *own = nullptr;                      // ownership counters of the solver, one word per block
     uint32_t own_pitch = 0;                       // transposed layout: 32 residue classes of own_pitch words
     uint32_t *counters = nullptr;                 // 8 words
@@ -184,8 +184,9 @@ void launch_sweep_t(RegArgs a, uint8_t *const flags[2], int relax_steps, int max
     int cur = 0;
     for (int i = 0; i < relax_steps; ++i, cur ^= 1) {
         a.flag_cur = flags[cur]; a.flag_next = flags[cur ^ 1];
-        hipLaunchKernelGGL(k_reg_iter<BS>, dim3((unsigned)((blocks + RegIter<BS>::PER_WG - 1) / RegIter<BS>::PER_WG)),
-                           dim3(256), 0, s, a);
+        constexpr int T = RegIter<BS>::T;
+        const unsigned tiles = (unsigned)(((a.cols + T - 1) / T) * ((a.rows + T - 1) / T));
+        hipLaunchKernelGGL(k_reg_iter<BS>, dim3(tiles), dim3(256), 0, s, a);
     }
     a.flag_cur = flags[cur]; a.flag_next = nullptr;
     hipLaunchKernelGGL(k_reg_solve<BS>, dim3(grid2), dim3(256), 0, s, a);
@@ -216,18 +217,20 @@ int launch_sweep(bbme_ctx *c, int level, int b, int mult)
     a.list0 = c->list[0]; a.list1 = c->list[1];
     a.own = c->own;
     a.own_pitch = c->own_pitch;
+    static const int rounds_env = getenv("BBME_LOCAL_ROUNDS") ? atoi(getenv("BBME_LOCAL_ROUNDS")) : 8;
+    a.local_rounds = std::max(1, rounds_env);
     static const int wide_env = getenv("BBME_WIDE_THRESHOLD") ? atoi(getenv("BBME_WIDE_THRESHOLD")) : 4;
     a.wide_threshold = (uint32_t)std::max(4, wide_env);
     a.counters = c->counters;
-    // relaxation steps: a step is one more launch (>= 5 us), which only the sweeps with heavy first generations
-    // repay -- measured on cfg3 / cfg4 (scripts/trace_table.py): large grids of small blocks, four steps for the first
-    // sweep of a block size (lambda has just doubled), two for the second
+    // relaxation launches (k_reg_iter, 8 local rounds per tile): one more launch (>= 5 us), which only the sweeps with
+    // heavy first generations repay -- measured on cfg3 / cfg4 / cfg2: large grids of small blocks, one launch per sweep
+    // (cfg4 -6 %, cfg2 -2 %, cfg3 neutral)
     const long long nblk = (long long)a.rows * a.cols;
     int steps = c->relax_steps;
     if (steps < 0) {
         // BBME_RELAX_RULE="min_blocks,max_b,steps_first,steps_second" (tuning knob)
         static long long min_blocks = 100000;
-        static int max_b = 4, s1 = 4, s2 = 2;
+        static int max_b = 4, s1 = 1, s2 = 1;
         static const bool parsed = [] {
             if (const char *e = getenv("BBME_RELAX_RULE")) sscanf(e, "%lld,%d,%d,%d", &min_blocks, &max_b, &s1, &s2);
             return true;

@@ -408,6 +408,7 @@ struct RegArgs {
     // marked when one of its already-updated inputs (L, UL, UR, U) has just been changed.
     uint8_t *flag_cur, *flag_next;
     uint32_t wide_threshold;    // solver: queue length above which a round uses the throughput form
+    int local_rounds;           // k_reg_iter: rounds a workgroup runs on its tile within one launch
     uint32_t *counters;         // [0..2] list lengths (rotating), [3] safety-net passes, [4] blocks re-evaluated,
                                 // [5] sticky: a sweep hit a cap without converging, [6] solver ticket
 };
@@ -735,51 +736,94 @@ __global__ __launch_bounds__(256) void k_reg_pass1(RegArgs a)
     }
 }
 
-// One relaxation step over the marked blocks, the whole chip at once, plain loads and stores: every
-// block marked in flag_cur is evaluated in place with the estimates as they are (an input that is being
-// rewritten in this very launch may be seen old or new -- if old, its writer marks this block again); a
-// block that changes marks its dependants in flag_next.  Asynchronous fixed-point iteration: any number
-// of these steps, followed by k_reg_solve, ends at the same (unique) field.  A step costs one launch; it
-// pays for itself on the first generations of a heavy sweep, where thousands of blocks are stale at once
-// and the solver's coherent traffic and memory-side atomics queue up.
-// a workgroup evaluates 256 / LPB blocks at a time; it scans four times that many, so that with up to a
-// quarter of the blocks marked it needs one round
+// Relaxation over the marked blocks, the whole chip at once, before the solver.  The grid is cut into tiles of
+// T x T blocks, one workgroup each.  A workgroup keeps the estimates of its tile (+ the ring of neighbours it reads:
+// one column left and right, one row above) in LDS, evaluates the marked blocks of the tile, and when a block
+// changes, queues its dependants R, DR, D, DL: those inside the tile for the workgroup's next LOCAL round (same
+// launch, a barrier apart), those outside in the byte map flag_next for the next launch.  After `local_rounds`
+// rounds whatever is still queued goes to flag_next too.  Plain loads and stores.  An estimate outside the tile is
+// read once, at the start; if its owner changes it during this launch, that owner marks the reader in flag_next.
+// This is asynchronous fixed-point iteration: any number of rounds or launches, followed by k_reg_solve, ends at
+// the same (unique) field.  It takes the first, heavy generations of a sweep -- thousands of stale blocks at once --
+// away from the solver, whose coherent traffic and memory-side atomics queue up under that load.
 template <int BS> struct RegIter {
-    static constexpr int PER_WG = 4 * 256 / RegCfg<BS>::LPB < 64 ? 64 : 4 * 256 / RegCfg<BS>::LPB;
+    static constexpr int T = BS <= 4 ? 32 : (BS == 8 ? 16 : 8);       // tile edge in blocks
 };
 template <int BS>
 __global__ __launch_bounds__(256) void k_reg_iter(RegArgs a)
 {
     constexpr int LPB = RegCfg<BS>::LPB;
-    constexpr int PER_WG = RegIter<BS>::PER_WG;               // blocks scanned by a workgroup
-    __shared__ uint32_t list[PER_WG];
-    __shared__ uint32_t n_marked;
-    if (threadIdx.x == 0) n_marked = 0;
-    __syncthreads();
-    const uint32_t nblocks = (uint32_t)a.rows * a.cols;
-    const uint32_t base = blockIdx.x * PER_WG;
-    uint32_t *words = reinterpret_cast<uint32_t *>(a.flag_cur);   // padded to a multiple of PER_WG bytes
-    for (int j = threadIdx.x; j < PER_WG / 4; j += 256) {
-        const uint32_t wi = base / 4 + j;
-        const uint32_t f = words[wi];
-        if (f) {
-            words[wi] = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (((f >> (8 * k)) & 0xffu) && wi * 4 + k < nblocks) list[atomicAdd(&n_marked, 1u)] = wi * 4 + k;
-        }
+    constexpr int T = RegIter<BS>::T;
+    constexpr int TP = T + 2;                                 // pitch of the LDS tile: halo column left and right
+    __shared__ mv_t tile[(T + 1) * TP];                       // row 0 = halo row above
+    __shared__ uint32_t list[2][T * T];
+    __shared__ uint32_t n_list[2];
+    __shared__ uint32_t queued[(T * T + 31) / 32];
+    const int t = threadIdx.x;
+    const int tiles_x = (a.cols + T - 1) / T;
+    const int r0 = ((int)blockIdx.x / tiles_x) * T, c0 = ((int)blockIdx.x % tiles_x) * T;
+    if (t < 2) n_list[t] = 0;
+    for (int i = t; i < (T + 1) * TP; i += 256) {
+        const int rr = r0 - 1 + i / TP, cc = c0 - 1 + i % TP;
+        tile[i] = (rr >= 0 && rr < a.rows && cc >= 0 && cc < a.cols) ? a.est[(size_t)rr * a.cols + cc] : 0u;
     }
     __syncthreads();
-    const uint32_t cnt = n_marked;
-    const int sub = threadIdx.x % LPB;
-    for (uint32_t idx = threadIdx.x / LPB; idx < cnt; idx += 256 / LPB) {
-        const uint32_t x = list[idx];
-        const int r = (int)(x / a.cols), c = (int)(x % a.cols);
-        const mv_t res = eval_block<BS, false>(a, r, c, sub, BBME_NEW_MASK);
-        if (sub == 0 && res != a.est[x]) {
-            a.est[x] = res;
-            mark_dependants(a, a.flag_next, r, c);
+    for (int i = t; i < T * T; i += 256) {                    // consume the tile's marks
+        const int lr = i / T, lc = i % T, rr = r0 + lr, cc = c0 + lc;
+        if (rr < a.rows && cc < a.cols) {
+            uint8_t *f = a.flag_cur + (size_t)rr * a.cols + cc;
+            if (*f) { *f = 0; list[0][atomicAdd(&n_list[0], 1u)] = (uint32_t)(lr * T + lc); }
         }
+    }
+    const int sub = t % LPB;
+    int cur = 0;
+    for (int round = 0;; ++round) {
+        __syncthreads();
+        const uint32_t cnt = n_list[cur];
+        if (cnt == 0) break;                                  // uniform
+        const bool last = round + 1 >= a.local_rounds;
+        __syncthreads();
+        if (t == 0) n_list[cur ^ 1] = 0;
+        for (int i = t; i < (T * T + 31) / 32; i += 256) queued[i] = 0;
+        __syncthreads();
+        for (uint32_t idx = t / LPB; idx < cnt; idx += 256 / LPB) {
+            const int lr = (int)(list[cur][idx] / T), lc = (int)(list[cur][idx] % T);
+            const int r = r0 + lr, c = c0 + lc;
+            mv_t cand[9];
+            uint32_t present = 0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int rr = r + kNbRow[k], cc = c + kNbCol[k];
+                if (rr >= 0 && rr < a.rows && cc >= 0 && cc < a.cols) present |= 1u << k;
+                const int rs = min(max(rr, 0), a.rows - 1), cs = min(max(cc, 0), a.cols - 1);
+                if ((BBME_NEW_MASK >> k) & 1u) cand[k] = tile[(lr + kNbRow[k] + 1) * TP + lc + kNbCol[k] + 1];
+                else cand[k] = a.old_grid[(size_t)(rs >> a.old_shift) * a.old_cols + (cs >> a.old_shift)];
+            }
+            bool uniform = true;
+#pragma unroll
+            for (int k = 1; k < 9; ++k) uniform &= !((present >> k) & 1u) || cand[k] == cand[0];
+            mv_t res = cand[0];
+            if (!uniform) res = score_block<BS, false>(a, cand, present, c * BS, r * BS, sub);
+            if (sub == 0 && res != tile[(lr + 1) * TP + lc + 1]) {
+                tile[(lr + 1) * TP + lc + 1] = res;
+                a.est[(size_t)r * a.cols + c] = res;
+                const int dr[4] = {0, 1, 1, 1}, dc[4] = {1, 1, 0, -1};
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int lr2 = lr + dr[d], lc2 = lc + dc[d], rr = r + dr[d], cc = c + dc[d];
+                    if (rr >= a.rows || cc < 0 || cc >= a.cols) continue;
+                    if (!last && lr2 < T && lc2 >= 0 && lc2 < T) {
+                        const uint32_t bit = (uint32_t)(lr2 * T + lc2);
+                        if (!(atomicOr(&queued[bit >> 5], 1u << (bit & 31u)) & (1u << (bit & 31u))))
+                            list[cur ^ 1][atomicAdd(&n_list[cur ^ 1], 1u)] = bit;
+                    } else {
+                        a.flag_next[(size_t)rr * a.cols + cc] = 1;
+                    }
+                }
+            }
+        }
+        if (last) break;                                      // uniform
+        cur ^= 1;
     }
 }
 
