@@ -189,7 +189,8 @@ void launch_sweep_t(RegArgs a, uint8_t *const flags[2], int relax_steps, int max
         hipLaunchKernelGGL(k_reg_iter<BS>, dim3(tiles), dim3(256), 0, s, a);
     }
     a.flag_cur = flags[cur]; a.flag_next = nullptr;
-    hipLaunchKernelGGL(k_reg_solve<BS>, dim3(grid2), dim3(256), 0, s, a);
+    static const int solve_waves = getenv("BBME_SOLVE_WAVES") ? std::max(1, std::min(4, atoi(getenv("BBME_SOLVE_WAVES")))) : 4;
+    hipLaunchKernelGGL(k_reg_solve<BS>, dim3(grid2), dim3(64 * (solve_waves == 3 ? 4 : solve_waves)), 0, s, a);
 }
 
 int launch_sweep(bbme_ctx *c, int level, int b, int mult)

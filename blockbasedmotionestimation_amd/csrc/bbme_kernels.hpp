@@ -909,7 +909,8 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
     // launch has a multiple of 8 workgroups; bands are whole scan chunks).
     constexpr uint32_t SCAN = 16;
     const uint32_t xcd = blockIdx.x & 7u;
-    const uint32_t w = (blockIdx.x >> 3) * 4 + wave, W = (gridDim.x >> 3) * 4;
+    const uint32_t wpw = blockDim.x >> 6;                  // waves per workgroup (1, 2 or 4)
+    const uint32_t w = (blockIdx.x >> 3) * wpw + wave, W = (gridDim.x >> 3) * wpw;
     const uint32_t band = ((nblocks + 8 * SCAN - 1) / (8 * SCAN)) * SCAN;
     const uint32_t band_begin = min(xcd * band, nblocks), band_end = min(band_begin + band, nblocks);
     uint32_t *ovf_list = a.list0;
@@ -1046,7 +1047,7 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
     if (threadIdx.x == 0) s_ticket = atomicAdd(&a.counters[6], 1u);
     __syncthreads();
     if (s_ticket != gridDim.x - 1) return;
-    drain_lists<BS>(a, threadIdx.x, 256);
+    drain_lists<BS>(a, threadIdx.x, (int)blockDim.x);
 }
 
 // =======================================================================================
