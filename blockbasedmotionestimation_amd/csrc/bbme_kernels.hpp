@@ -598,27 +598,38 @@ struct PhaseProf;
 #define BBME_PHASE(p, i) ((void)0)
 #endif
 
-template <int BS, bool COHERENT>
-__device__ __forceinline__ mv_t eval_block_lanes(const RegArgs &a, int r, int c, int k16, uint32_t use_new,
-                                                 PhaseProf *prof = nullptr)
+// Which estimate lane k16 of a 16-lane group reads for block (r, c): candidate k = k16 (lanes 9..15
+// shadow candidate 0 and are ignored).
+struct LaneCand {
+    const mv_t *src;            // where the candidate's MV lives (est for the already-updated inputs, else old_grid)
+    bool present;               // k16 < 9 and the neighbour exists
+};
+__device__ __forceinline__ LaneCand lanes_candidate(const RegArgs &a, int r, int c, int k16, uint32_t use_new)
+{
+    // (drow + 1) and (dcol + 1) of candidate k, two bits each, order C,L,R,DR,UL,UR,U,D,DL (:441-449)
+    constexpr uint32_t kRowCode = 1u | 1u << 2 | 1u << 4 | 2u << 6 | 0u << 8 | 0u << 10 | 0u << 12 | 2u << 14 | 2u << 16;
+    constexpr uint32_t kColCode = 1u | 0u << 2 | 2u << 4 | 2u << 6 | 0u << 8 | 2u << 10 | 1u << 12 | 1u << 14 | 0u << 16;
+    const int k = k16 < 9 ? k16 : 0;
+    const int rr = r + (int)((kRowCode >> (2 * k)) & 3u) - 1, cc = c + (int)((kColCode >> (2 * k)) & 3u) - 1;
+    LaneCand lc;
+    lc.present = k16 < 9 && rr >= 0 && rr < a.rows && cc >= 0 && cc < a.cols;
+    const int rs = min(max(rr, 0), a.rows - 1), cs = min(max(cc, 0), a.cols - 1);
+    // one load instruction for all lanes (a divergent if / else would cost two memory trips): the
+    // already-updated inputs come from `est`, the others from `old_grid`, all through the coherent path
+    lc.src = ((use_new >> k) & 1u) ? a.est + (size_t)rs * a.cols + cs
+                                   : a.old_grid + (size_t)(rs >> a.old_shift) * a.old_cols + (cs >> a.old_shift);
+    return lc;
+}
+
+// Second half: lane k16 of the group holds candidate k16's MV `mv`; every lane of the group returns the winner.
+template <int BS>
+__device__ __forceinline__ mv_t lanes_score(const RegArgs &a, int r, int c, int k16, bool present, mv_t mv,
+                                            PhaseProf *prof = nullptr)
 {
 #pragma clang fp contract(off)
     constexpr int NW = BS >= 4 ? BS / 4 : 1;
     struct __attribute__((packed, aligned(1))) row_t { uint32_t v[NW]; };
     constexpr uint32_t kMask = BS >= 4 ? 0xffffffffu : 0x0000ffffu;
-    // (drow + 1) and (dcol + 1) of candidate k, two bits each, order C,L,R,DR,UL,UR,U,D,DL (:441-449)
-    constexpr uint32_t kRowCode = 1u | 1u << 2 | 1u << 4 | 2u << 6 | 0u << 8 | 0u << 10 | 0u << 12 | 2u << 14 | 2u << 16;
-    constexpr uint32_t kColCode = 1u | 0u << 2 | 2u << 4 | 2u << 6 | 0u << 8 | 2u << 10 | 1u << 12 | 1u << 14 | 0u << 16;
-    const int k = k16 < 9 ? k16 : 0;                          // lanes 9..15 shadow candidate 0 and are ignored
-    const int rr = r + (int)((kRowCode >> (2 * k)) & 3u) - 1, cc = c + (int)((kColCode >> (2 * k)) & 3u) - 1;
-    const bool present = k16 < 9 && rr >= 0 && rr < a.rows && cc >= 0 && cc < a.cols;
-    const int rs = min(max(rr, 0), a.rows - 1), cs = min(max(cc, 0), a.cols - 1);
-    // one load instruction for all lanes (a divergent if / else would cost two memory trips): the
-    // already-updated inputs come from `est`, the others from `old_grid`, all through the coherent path
-    const mv_t *src = ((use_new >> k) & 1u) ? a.est + (size_t)rs * a.cols + cs
-                                            : a.old_grid + (size_t)(rs >> a.old_shift) * a.old_cols + (cs >> a.old_shift);
-    const mv_t mv = load_est<COHERENT>(src);
-    BBME_PHASE(prof, 0);                                      // queue pop + address arithmetic + gather trip
     const int bx = c * BS, by = r * BS;
     int x2 = bx + mv_x(mv), y2 = by + mv_y(mv);
     const bool inside = present && !(x2 < 0 || x2 > a.width - BS || y2 < 0 || y2 > a.height - BS);   // :578
@@ -672,6 +683,16 @@ __device__ __forceinline__ mv_t eval_block_lanes(const RegArgs &a, int r, int c,
 #undef BBME_ARGMIN_STEP
     BBME_PHASE(prof, 2);                                      // smoothness + energy + argmin
     return winner;
+}
+
+template <int BS, bool COHERENT>
+__device__ __forceinline__ mv_t eval_block_lanes(const RegArgs &a, int r, int c, int k16, uint32_t use_new,
+                                                 PhaseProf *prof = nullptr)
+{
+    const LaneCand lc = lanes_candidate(a, r, c, k16, use_new);
+    const mv_t mv = load_est<COHERENT>(lc.src);
+    BBME_PHASE(prof, 0);                                      // queue pop + address arithmetic + gather trip
+    return lanes_score<BS>(a, r, c, k16, lc.present, mv, prof);
 }
 
 // ---- work-list state ---------------------------------------------------------------------
@@ -776,49 +797,79 @@ __global__ __launch_bounds__(256) void k_reg_iter(RegArgs a)
         }
     }
     const int sub = t % LPB;
-    int cur = 0;
+    int cur = 0, heavy = 0;
+    // a block changed: its dependants go on the tile's next list (once) or, outside the tile, into the byte map
+    auto propagate = [&](int lr, int lc, int r, int c, bool last) {
+        const int dr[4] = {0, 1, 1, 1}, dc[4] = {1, 1, 0, -1};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int lr2 = lr + dr[d], lc2 = lc + dc[d], rr = r + dr[d], cc = c + dc[d];
+            if (rr >= a.rows || cc < 0 || cc >= a.cols) continue;
+            if (!last && lr2 < T && lc2 >= 0 && lc2 < T) {
+                const uint32_t bit = (uint32_t)(lr2 * T + lc2);
+                if (!(atomicOr(&queued[bit >> 5], 1u << (bit & 31u)) & (1u << (bit & 31u))))
+                    list[cur ^ 1][atomicAdd(&n_list[cur ^ 1], 1u)] = bit;
+            } else {
+                a.flag_next[(size_t)rr * a.cols + cc] = 1;
+            }
+        }
+    };
     for (int round = 0;; ++round) {
         __syncthreads();
         const uint32_t cnt = n_list[cur];
         if (cnt == 0) break;                                  // uniform
-        const bool last = round + 1 >= a.local_rounds;
+        // rounds with many blocks keep one CU busy while the chip waits: only `local_rounds` of them; rounds with
+        // up to 16 blocks are a chain being walked, which is cheapest right here (estimates in LDS, no atomics)
+        const bool chain = cnt <= 16u;
+        if (!chain) ++heavy;
+        const bool last = heavy >= a.local_rounds || round + 1 >= 96;
         __syncthreads();
         if (t == 0) n_list[cur ^ 1] = 0;
         for (int i = t; i < (T * T + 31) / 32; i += 256) queued[i] = 0;
         __syncthreads();
-        for (uint32_t idx = t / LPB; idx < cnt; idx += 256 / LPB) {
-            const int lr = (int)(list[cur][idx] / T), lc = (int)(list[cur][idx] % T);
-            const int r = r0 + lr, c = c0 + lc;
-            mv_t cand[9];
-            uint32_t present = 0;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
+        if (chain) {
+            // 16 lanes per block, lane k = candidate k (see eval_block_lanes)
+            const int g = t >> 4, k16 = t & 15;
+            if ((uint32_t)g < cnt) {
+                const int lr = (int)(list[cur][g] / T), lc = (int)(list[cur][g] % T);
+                const int r = r0 + lr, c = c0 + lc;
+                const int k = k16 < 9 ? k16 : 0;
                 const int rr = r + kNbRow[k], cc = c + kNbCol[k];
-                if (rr >= 0 && rr < a.rows && cc >= 0 && cc < a.cols) present |= 1u << k;
+                const bool present = k16 < 9 && rr >= 0 && rr < a.rows && cc >= 0 && cc < a.cols;
                 const int rs = min(max(rr, 0), a.rows - 1), cs = min(max(cc, 0), a.cols - 1);
-                if ((BBME_NEW_MASK >> k) & 1u) cand[k] = tile[(lr + kNbRow[k] + 1) * TP + lc + kNbCol[k] + 1];
-                else cand[k] = a.old_grid[(size_t)(rs >> a.old_shift) * a.old_cols + (cs >> a.old_shift)];
+                mv_t mv;
+                if ((BBME_NEW_MASK >> k) & 1u) mv = tile[(lr + kNbRow[k] + 1) * TP + lc + kNbCol[k] + 1];
+                else mv = a.old_grid[(size_t)(rs >> a.old_shift) * a.old_cols + (cs >> a.old_shift)];
+                const mv_t res = lanes_score<BS>(a, r, c, k16, present, mv);
+                if (k16 == 0 && res != tile[(lr + 1) * TP + lc + 1]) {
+                    tile[(lr + 1) * TP + lc + 1] = res;
+                    a.est[(size_t)r * a.cols + c] = res;
+                    propagate(lr, lc, r, c, last);
+                }
             }
-            bool uniform = true;
+        } else {
+            for (uint32_t idx = t / LPB; idx < cnt; idx += 256 / LPB) {
+                const int lr = (int)(list[cur][idx] / T), lc = (int)(list[cur][idx] % T);
+                const int r = r0 + lr, c = c0 + lc;
+                mv_t cand[9];
+                uint32_t present = 0;
 #pragma unroll
-            for (int k = 1; k < 9; ++k) uniform &= !((present >> k) & 1u) || cand[k] == cand[0];
-            mv_t res = cand[0];
-            if (!uniform) res = score_block<BS, false>(a, cand, present, c * BS, r * BS, sub);
-            if (sub == 0 && res != tile[(lr + 1) * TP + lc + 1]) {
-                tile[(lr + 1) * TP + lc + 1] = res;
-                a.est[(size_t)r * a.cols + c] = res;
-                const int dr[4] = {0, 1, 1, 1}, dc[4] = {1, 1, 0, -1};
+                for (int k = 0; k < 9; ++k) {
+                    const int rr = r + kNbRow[k], cc = c + kNbCol[k];
+                    if (rr >= 0 && rr < a.rows && cc >= 0 && cc < a.cols) present |= 1u << k;
+                    const int rs = min(max(rr, 0), a.rows - 1), cs = min(max(cc, 0), a.cols - 1);
+                    if ((BBME_NEW_MASK >> k) & 1u) cand[k] = tile[(lr + kNbRow[k] + 1) * TP + lc + kNbCol[k] + 1];
+                    else cand[k] = a.old_grid[(size_t)(rs >> a.old_shift) * a.old_cols + (cs >> a.old_shift)];
+                }
+                bool uniform = true;
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const int lr2 = lr + dr[d], lc2 = lc + dc[d], rr = r + dr[d], cc = c + dc[d];
-                    if (rr >= a.rows || cc < 0 || cc >= a.cols) continue;
-                    if (!last && lr2 < T && lc2 >= 0 && lc2 < T) {
-                        const uint32_t bit = (uint32_t)(lr2 * T + lc2);
-                        if (!(atomicOr(&queued[bit >> 5], 1u << (bit & 31u)) & (1u << (bit & 31u))))
-                            list[cur ^ 1][atomicAdd(&n_list[cur ^ 1], 1u)] = bit;
-                    } else {
-                        a.flag_next[(size_t)rr * a.cols + cc] = 1;
-                    }
+                for (int k = 1; k < 9; ++k) uniform &= !((present >> k) & 1u) || cand[k] == cand[0];
+                mv_t res = cand[0];
+                if (!uniform) res = score_block<BS, false>(a, cand, present, c * BS, r * BS, sub);
+                if (sub == 0 && res != tile[(lr + 1) * TP + lc + 1]) {
+                    tile[(lr + 1) * TP + lc + 1] = res;
+                    a.est[(size_t)r * a.cols + c] = res;
+                    propagate(lr, lc, r, c, last);
                 }
             }
         }
