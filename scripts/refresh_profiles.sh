@@ -4,7 +4,7 @@
 # Afterwards, locally: scripts/pmc_report.py on the two pmc directories, copy the stats csv and the bench line.
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/refresh
-rm -rf $OUT && mkdir -p $OUT
+rm -rf $OUT && mkdir -p $OUT      # NB: clean gpurun_out/refresh locally too before merging a new run
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 python3 $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 echo "bench done"
