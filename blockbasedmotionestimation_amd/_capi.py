@@ -76,6 +76,7 @@ SIGNATURES = {
     "bbme_get_cells_host": (C.c_int, [_ctx, C.c_void_p]),
     "bbme_cells_device": (C.c_int, [_ctx, _P(C.c_void_p)]),
     "bbme_expand_cells_device": (C.c_int, [_ctx, C.c_void_p, C.c_void_p]),
+    "bbme_expand_cells_device_on": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bbme_stage_search": (C.c_int, [_ctx, C.c_int]),
     "bbme_stage_regularize": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int]),
     "bbme_stage_get_mvs": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p]),

@@ -644,13 +644,19 @@ int bbme_cells_device(bbme_ctx *c, const int16_t **d_cells)
 
 int bbme_expand_cells_device(bbme_ctx *c, const int16_t *d_cells, float *d_flow)
 {
+    return bbme_expand_cells_device_on(c, d_cells, d_flow, nullptr);
+}
+
+int bbme_expand_cells_device_on(bbme_ctx *c, const int16_t *d_cells, float *d_flow, void *hip_stream)
+{
     if (int rc = check_ctx(c)) return rc;
     if (!d_cells || !d_flow) return bbme::fail(BBME_ERR_INVALID, "null pointer");
     HIP_TRY(hipSetDevice(c->device));
     Level &L = c->lv[0];
     const int cc = L.width / 2, cr = L.height / 2;
     const long long threads = (long long)cc * cr * 2;
-    hipLaunchKernelGGL(k_expand, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(k_expand, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                       hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream,
                        reinterpret_cast<const mv_t *>(d_cells), cc, cr, d_flow, L.width);
     HIP_TRY(hipGetLastError());
     return BBME_OK;

@@ -138,9 +138,11 @@ class MF:
         _capi.check(self._lib.bbme_cells_device(self._ctx, C.byref(p)))
         return p.value
 
-    def expand_cells_device(self, cells_ptr, flow_ptr):
-        """copy_to_all_pixels for a cell grid anywhere in HBM -> dense padded field (device pointers)."""
-        _capi.check(self._lib.bbme_expand_cells_device(self._ctx, C.c_void_p(cells_ptr), C.c_void_p(flow_ptr)))
+    def expand_cells_device(self, cells_ptr, flow_ptr, hip_stream_handle=None):
+        """copy_to_all_pixels for a cell grid anywhere in HBM -> dense padded field (device pointers), on the
+        context's stream or on the given HIP stream."""
+        _capi.check(self._lib.bbme_expand_cells_device_on(self._ctx, C.c_void_p(cells_ptr), C.c_void_p(flow_ptr),
+                                                          C.c_void_p(hip_stream_handle or 0)))
 
     def calcMotionBlockMatching(self):
         """cv::Mat MF::calcMotionBlockMatching() -- dense padded (H, W, 2) float32 (u, v) field."""

@@ -140,6 +140,9 @@ int bbme_cells_device(bbme_ctx *ctx, const int16_t **d_cells);
 /* copy_to_all_pixels (:815-826) for a cell grid that lives anywhere in HBM (e.g. gathered from
  * another GPU): writes the dense padded H0 x W0 float2 field to d_flow, on the ctx stream. */
 int bbme_expand_cells_device(bbme_ctx *ctx, const int16_t *d_cells, float *d_flow);
+/* The same on a caller-supplied HIP stream (NULL = the ctx stream), e.g. the stream a gather completes on,
+ * so that the expansion of one step's results overlaps the next step's estimate. */
+int bbme_expand_cells_device_on(bbme_ctx *ctx, const int16_t *d_cells, float *d_flow, void *hip_stream);
 int bbme_get_cells_host(bbme_ctx *ctx, int16_t *cells);
 
 /* ---- single stages, for parity tests against the reference's private methods -------- */

@@ -347,6 +347,25 @@ def test_1080p_pair_against_oracle(bbme, oracle):
     assert np.array_equal(got, exp) and np.array_equal(again, exp)
 
 
+def test_4k_uncorrelated_frames_against_oracle(bbme, oracle):
+    """BASELINE configs[2] geometry (4K, 16x16, +-32, 4 levels) on the worst content for the regulariser: two
+    unrelated noise frames, so that nearly every block changes in nearly every sweep (long queues, relaxation
+    launches, overflow list).  The oracle needs a few seconds here because its searches hit the image border early."""
+    rng = np.random.default_rng(5)
+    f1 = rng.integers(0, 256, (2160, 3840), dtype=np.uint8)
+    f2 = rng.integers(0, 256, (2160, 3840), dtype=np.uint8)
+    search, block = [80] * 4, [16] * 4
+    mf = bbme.MF(f1, f2, search, block, 4)
+    got = mf.calcMotionBlockMatching()
+    flag, _ = mf.last_sweep_passes()
+    mf.close()
+    omf = oracle.OracleMF(f1, f2, search, block, use_cache=False)
+    exp = omf.calc_motion_block_matching()
+    omf.close()
+    assert flag == 0, "a sweep hit its round cap"
+    assert np.array_equal(got, exp)
+
+
 def test_pipelined_sequence_matches_oracle_per_pair(bbme, oracle):
     """A sequence on one GPU with several pairs in flight (contexts re-used round-robin with new frames):
     every pair's field is the oracle's, whatever else is running beside it."""
