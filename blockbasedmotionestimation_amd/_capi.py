@@ -74,6 +74,7 @@ SIGNATURES = {
     "bbme_flow_device": (C.c_int, [_ctx, _P(C.c_void_p)]),
     "bbme_get_flow_host": (C.c_int, [_ctx, C.c_void_p]),
     "bbme_get_cells_host": (C.c_int, [_ctx, C.c_void_p]),
+    "bbme_calculate_mse_device": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, _P(C.c_double)]),
     "bbme_cells_device": (C.c_int, [_ctx, _P(C.c_void_p)]),
     "bbme_expand_cells_device": (C.c_int, [_ctx, C.c_void_p, C.c_void_p]),
     "bbme_expand_cells_device_on": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -662,6 +662,40 @@ int bbme_expand_cells_device_on(bbme_ctx *c, const int16_t *d_cells, float *d_fl
     return BBME_OK;
 }
 
+int bbme_calculate_mse_device(bbme_ctx *c, const float *d_gtruth, int gt_width, int gt_height, int scale, double *out)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (!d_gtruth || !out || gt_width < 1 || gt_height < 1 || scale < 1)
+        return bbme::fail(BBME_ERR_INVALID, "bbme_calculate_mse_device: bad arguments");
+    Level &L = c->lv[0];
+    if (L.cur_block != 2) return bbme::fail(BBME_ERR_STATE, "level 0 has not been regularised down to 2x2 blocks");
+    if ((long long)(gt_width - 1) * scale >= c->geom.width || (long long)(gt_height - 1) * scale >= c->geom.height)
+        return bbme::fail(BBME_ERR_INVALID, "ground truth %dx%d at scale %d does not fit the %dx%d frame",
+                          gt_width, gt_height, scale, c->geom.width, c->geom.height);
+    HIP_TRY(hipSetDevice(c->device));
+    constexpr int kMaxGroups = 512;
+    const long long n = (long long)gt_width * gt_height;
+    const int groups = (int)std::min<long long>(kMaxGroups, (n + 255) / 256);
+    double *d_sum = nullptr;
+    HIP_TRY(hipMalloc(&d_sum, kMaxGroups * (sizeof(double) + sizeof(unsigned long long))));
+    unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>(d_sum + kMaxGroups);
+    hipLaunchKernelGGL(k_epe, dim3(groups), dim3(256), 0, c->stream, L.grid[L.cur], L.width / 2,
+                       c->geom.pad_x, c->geom.pad_y, scale, d_gtruth, gt_width, gt_height, d_sum, d_cnt);
+    std::vector<double> h_sum(kMaxGroups);
+    std::vector<unsigned long long> h_cnt(kMaxGroups);
+    hipError_t err = hipGetLastError();
+    if (err == hipSuccess) err = hipMemcpyAsync(h_sum.data(), d_sum, groups * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (err == hipSuccess) err = hipMemcpyAsync(h_cnt.data(), d_cnt, groups * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_sum);
+    if (err != hipSuccess) return bbme::fail(BBME_ERR_HIP, "bbme_calculate_mse_device: %s", hipGetErrorString(err));
+    double error = 0;
+    unsigned long long count = 0;
+    for (int i = 0; i < groups; ++i) { error += h_sum[i]; count += h_cnt[i]; }
+    *out = error / (double)count;                     // 0/0 = NaN when no pixel is known, as in the reference (:330)
+    return BBME_OK;
+}
+
 int bbme_stage_search(bbme_ctx *c, int level)
 {
     if (int rc = check_level(c, level)) return rc;

@@ -1120,6 +1120,42 @@ __global__ __launch_bounds__(256) void k_expand(const mv_t *cells, int cell_cols
 }
 
 // =======================================================================================
+// Flow::CalculateMSE (rw_flow.cpp:309-332) fused with the driver's subsampling (main_class.cpp:58-70): end-point
+// error between a ground-truth field and the result at every `scale`-th pixel of the unpadded frame, divided by
+// `scale`, straight from the 2x2-cell grid.  float arithmetic per pixel as in the reference's expression, double
+// sums; every workgroup leaves one partial sum and one count, the host adds them in index order.
+// =======================================================================================
+__global__ __launch_bounds__(256) void k_epe(const mv_t *cells, int cell_cols, int pad_x, int pad_y, int scale,
+                                             const float *gtruth, int gt_width, int gt_height,
+                                             double *partial_sum, unsigned long long *partial_cnt)
+{
+#pragma clang fp contract(off)
+    __shared__ double s_sum[256];
+    __shared__ unsigned long long s_cnt[256];
+    const long long n = (long long)gt_width * gt_height;
+    double sum = 0;
+    unsigned long long cnt = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float gu = gtruth[2 * i], gv = gtruth[2 * i + 1];
+        if (fabsf(gu) > 1e9f || fabsf(gv) > 1e9f || isnan(gu) || isnan(gv)) continue;     // unknown_flow :39-43
+        const int y = pad_y + scale * (int)(i / gt_width), x = pad_x + scale * (int)(i % gt_width);
+        const mv_t m = cells[(size_t)(y >> 1) * cell_cols + (x >> 1)];
+        const float eu = (float)mv_x(m) / (float)scale, ev = (float)mv_y(m) / (float)scale;
+        const float du = gu - eu, dv = gv - ev;
+        const float sq = du * du + dv * dv;
+        sum += (double)sqrtf(sq);
+        ++cnt;
+    }
+    s_sum[threadIdx.x] = sum; s_cnt[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { s_sum[threadIdx.x] += s_sum[threadIdx.x + o]; s_cnt[threadIdx.x] += s_cnt[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partial_sum[blockIdx.x] = s_sum[0]; partial_cnt[blockIdx.x] = s_cnt[0]; }
+}
+
+// =======================================================================================
 // MF::MF on the GPU (motion_framework.cpp:57-61, 86-106): zero border and pyrDown cascade.
 // =======================================================================================
 __global__ __launch_bounds__(256) void k_pad_zero(const uint8_t *src, int width, int height, int pitch,

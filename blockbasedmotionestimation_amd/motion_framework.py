@@ -144,6 +144,16 @@ class MF:
         _capi.check(self._lib.bbme_expand_cells_device_on(self._ctx, C.c_void_p(cells_ptr), C.c_void_p(flow_ptr),
                                                           C.c_void_p(hip_stream_handle or 0)))
 
+    def calculate_mse_device(self, gtruth, scale=4):
+        """Flow::CalculateMSE against a ground-truth field already in HBM (torch float32 CUDA tensor (h, w, 2)),
+        fused with the driver's every-`scale`-th-pixel / `scale` subsampling; nothing is downloaded but the sums."""
+        assert gtruth.is_cuda and gtruth.is_contiguous() and gtruth.dim() == 3 and gtruth.shape[2] == 2
+        assert gtruth.dtype.itemsize == 4 and gtruth.dtype.is_floating_point
+        out = C.c_double()
+        _capi.check(self._lib.bbme_calculate_mse_device(self._ctx, C.c_void_p(gtruth.data_ptr()), gtruth.shape[1],
+                                                        gtruth.shape[0], int(scale), C.byref(out)))
+        return out.value
+
     def calcMotionBlockMatching(self):
         """cv::Mat MF::calcMotionBlockMatching() -- dense padded (H, W, 2) float32 (u, v) field."""
         self.estimate_async()

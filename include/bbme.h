@@ -144,6 +144,13 @@ int bbme_expand_cells_device(bbme_ctx *ctx, const int16_t *d_cells, float *d_flo
  * so that the expansion of one step's results overlaps the next step's estimate. */
 int bbme_expand_cells_device_on(bbme_ctx *ctx, const int16_t *d_cells, float *d_flow, void *hip_stream);
 int bbme_get_cells_host(bbme_ctx *ctx, int16_t *cells);
+/* Flow::CalculateMSE (rw_flow.cpp:309-332) on the device, fused with the driver's subsampling
+ * (main_class.cpp:58-70): mean end-point error between a ground-truth field in HBM (gt_width x gt_height,
+ * u,v interleaved) and the context's current result taken at every `scale`-th pixel of the unpadded frame and
+ * divided by `scale` (4 for the reference's pipeline, 1 for none).  Per-pixel arithmetic is the reference's
+ * float expression; the double sum is taken in a different order, so it agrees with bbme_calculate_mse to
+ * about 1e-12 relative, not bit for bit.  Synchronises the ctx stream. */
+int bbme_calculate_mse_device(bbme_ctx *ctx, const float *d_gtruth, int gt_width, int gt_height, int scale, double *out);
 
 /* ---- single stages, for parity tests against the reference's private methods -------- */
 

@@ -308,6 +308,17 @@ def test_epe_against_middlebury_ground_truth_warped_pair(bbme, oracle):
     assert np.array_equal(sub, osub)
     assert epe == oracle.calculate_mse(gt, osub)
     assert epe < 0.6, "average end-point error %.3f px" % epe
+    # the same number without downloading the field: EPE reduced on the device from the 2x2-cell grid.  Per-pixel
+    # arithmetic is the reference's; only the order of the double sum differs -> 1e-12 relative
+    import torch
+    gt_holes = gt.copy()
+    gt_holes[7:19, 30:60] = 1.666666752e9
+    gt_holes[100, 100, 0] = np.nan
+    for g in (gt, gt_holes):
+        dev = mf.calculate_mse_device(torch.from_numpy(g).cuda(), scale=4)
+        assert dev == pytest.approx(oracle.calculate_mse(g, osub), rel=1e-12)
+    with pytest.raises(bbme.BbmeError):
+        mf.calculate_mse_device(torch.zeros((h + 8, w, 2), dtype=torch.float32, device="cuda"), scale=4)
     mf.close()
 
 
