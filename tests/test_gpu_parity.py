@@ -222,6 +222,13 @@ def test_full_pipeline_host_frames(bbme, oracle):
     mf.synchronize()
     assert np.array_equal(dense.cpu().numpy(), exp)
     assert np.array_equal(np.repeat(np.repeat(cells, 2, 0), 2, 1).astype(np.float32), exp)
+    # ... and on a stream of the caller's (the one a gather completes on)
+    side = torch.cuda.Stream()
+    dense2 = torch.zeros((448, 640, 2), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    mf.expand_cells_device(moved.data_ptr(), dense2.data_ptr(), side.cuda_stream)
+    side.synchronize()
+    assert np.array_equal(dense2.cpu().numpy(), exp)
     mf.close()
 
 
