@@ -249,6 +249,31 @@ def main():
         for c in ctxs[1:]:
             c.close()
 
+    # the boundary with host buffers (never `value`): frames in (pinned) host memory -> upload (2 x 8.3 MB at 4K), padding +
+    # pyramid on the GPU, estimate, download of the dense field (66.8 MB) or of the compact 2x2-cell grid (4.2 MB)
+    host_boundary = None
+    if rank == 0 and not use_dist:
+        p1, p2 = torch.from_numpy(f1).pin_memory(), torch.from_numpy(f2).pin_memory()
+        reps = 5
+
+        def through_host(get):
+            mf.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                t1.copy_(p1, non_blocking=True)
+                t2.copy_(p2, non_blocking=True)
+                torch.cuda.synchronize()
+                mf.set_frames_device(t1, t2)
+                mf.estimate_async()
+                get()
+            return (time.perf_counter() - t0) / reps * 1e3
+        dense_ms = through_host(mf.get_flow)
+        cells_ms = through_host(mf.get_cells)
+        host_boundary = {"host_frames_to_dense_field_ms": round(dense_ms, 2), "host_frames_to_cells_ms": round(cells_ms, 2),
+                         "value_with_dense_download": round(blocks[0] / dense_ms / 1e3, 3),
+                         "value_with_cells_download": round(blocks[0] / cells_ms / 1e3, 3), "unit": "Mblocks/s",
+                         "note": "upload of the two frames, padding + pyramid on the GPU, estimate, download into pageable numpy memory"}
+
     # per-kernel timing with HIP events on the ctx stream (eager launches, same kernels and data)
     prof = None
     if rank == 0:
@@ -321,6 +346,8 @@ def main():
                               "unit": "GB/s", "frac": round(reg_gbs / HBM_PEAK_GBS, 5)}
         if sequence is not None:
             out["sequence"] = sequence
+        if host_boundary is not None:
+            out["host_boundary"] = host_boundary
         out["epe_vs_middlebury_gt"] = epe_on_ground_truth(bbme, local_rank)
         if not args.no_cpu_baseline:
             dt, parity = cpu_baseline(f1, f2, search, block, levels, result_flow)
