@@ -118,13 +118,23 @@ class MF:
     def synchronize(self):
         _capi.check(self._lib.bbme_synchronize(self._ctx))
 
-    def get_flow(self):
-        out = np.empty((self.padded_height, self.padded_width, 2), np.float32)
+    def get_flow(self, out=None):
+        """The dense padded field; `out` may be a preallocated C-contiguous float32 array of that shape, e.g. a view
+        of pinned memory (the 66.8 MB of a 4K field download about three times faster into pinned memory)."""
+        shape = (self.padded_height, self.padded_width, 2)
+        if out is None:
+            out = np.empty(shape, np.float32)
+        elif out.shape != shape or out.dtype != np.float32 or not out.flags.c_contiguous:
+            raise _capi.BbmeError(_capi.ERR_INVALID, "get_flow: out must be a C-contiguous float32 array of shape %s" % (shape,))
         _capi.check(self._lib.bbme_get_flow_host(self._ctx, out.ctypes.data))
         return out
 
-    def get_cells(self):
-        out = np.empty((self.padded_height // 2, self.padded_width // 2, 2), np.int16)
+    def get_cells(self, out=None):
+        shape = (self.padded_height // 2, self.padded_width // 2, 2)
+        if out is None:
+            out = np.empty(shape, np.int16)
+        elif out.shape != shape or out.dtype != np.int16 or not out.flags.c_contiguous:
+            raise _capi.BbmeError(_capi.ERR_INVALID, "get_cells: out must be a C-contiguous int16 array of shape %s" % (shape,))
         _capi.check(self._lib.bbme_get_cells_host(self._ctx, out.ctypes.data))
         return out
 
