@@ -214,6 +214,15 @@ def test_full_pipeline_host_frames(bbme, oracle):
     assert np.array_equal(mf.calcMotionBlockMatching(), exp)
     cells = mf.get_cells()
     assert np.array_equal(cells.astype(np.float32), exp[::2, ::2])
+    # caller-supplied output arrays (e.g. views of pinned memory)
+    buf = np.zeros((448, 640, 2), np.float32)
+    assert mf.get_flow(buf) is buf and np.array_equal(buf, exp)
+    cbuf = np.zeros((224, 320, 2), np.int16)
+    assert mf.get_cells(cbuf) is cbuf and np.array_equal(cbuf, cells)
+    with pytest.raises(bbme.BbmeError):
+        mf.get_flow(np.zeros((448, 640, 2), np.float64))
+    with pytest.raises(bbme.BbmeError):
+        mf.get_cells(np.zeros((224, 321, 2), np.int16))
     # the multi-GPU path: a cell grid copied elsewhere in HBM (as after a gather) expands to the same field
     import torch
     moved = torch.from_numpy(cells.copy()).cuda()
