@@ -83,23 +83,47 @@ def epe_on_ground_truth(bbme, device):
                     "4 levels, 32x32 blocks, search 64"}
 
 
+def cpu_info():
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count()
+    return model, os.cpu_count(), usable
+
+
 def cpu_baseline(f1, f2, search, block, levels, expect_flow):
-    """The oracle (CPU restatement, 1 thread, rebuilt here with -march=native) timed on the same pair."""
-    src = os.path.join(ROOT, "oracle", "bbme_oracle.c")
-    out = os.path.join(tempfile.mkdtemp(prefix="bbme_cpu_"), "liboracle_native.so")
-    subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-shared", "-ffp-contract=off",
-                           "-o", out, src, "-lm"])
+    """The oracle (CPU restatement, rebuilt here with -O3 -march=native) timed on the same pair, whole pyramid, as the
+    reference times calcMotionBlockMatching (main_class.cpp:47-55): (i) one thread, like the reference; (ii) the
+    search's macroblock loop spread over all usable host cores with OpenMP (the regulariser sweeps stay sequential:
+    they are order dependent).  Returns [(seconds, threads, parity)] for the two legs."""
     from oracle import bbme_oracle as O
-    import ctypes as C
-    O._LIB_PATH = out            # load the native build instead of the portable one
-    O._lib = None
-    omf = O.OracleMF(f1, f2, [search] * levels, [block] * levels, use_cache=False)
-    t0 = time.perf_counter()
-    flow = omf.calc_motion_block_matching()
-    dt = time.perf_counter() - t0
-    omf.close()
-    parity = bool(np.array_equal(flow, expect_flow)) if expect_flow is not None else None
-    return dt, parity
+    src = os.path.join(ROOT, "oracle", "bbme_oracle.c")
+    tmp = tempfile.mkdtemp(prefix="bbme_cpu_")
+    _, _, usable = cpu_info()
+    legs = []
+    for name, flags, threads in (("st", [], 1), ("omp", ["-fopenmp"], usable)):
+        out = os.path.join(tmp, "liboracle_native_%s.so" % name)
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-shared", "-ffp-contract=off"] + flags +
+                              ["-o", out, src, "-lm"])
+        os.environ["OMP_NUM_THREADS"] = str(threads)
+        O._LIB_PATH = out            # load the native build instead of the portable one
+        O._lib = None
+        omf = O.OracleMF(f1, f2, [search] * levels, [block] * levels, use_cache=False)
+        t0 = time.perf_counter()
+        flow = omf.calc_motion_block_matching()
+        dt = time.perf_counter() - t0
+        omf.close()
+        parity = bool(np.array_equal(flow, expect_flow)) if expect_flow is not None else None
+        legs.append((dt, threads, parity))
+    return legs
 
 
 def main():
@@ -144,60 +168,26 @@ def main():
     pw, ph = mf.padded_width, mf.padded_height
     blocks = level_blocks(pw, ph, block, levels)
 
-    # Multi-GPU: everything runs on torch's current stream (one order for kernels and collectives).
-    # Each rank's result travels as the compact cell grid -- one int16 (dx, dy) pair per 2x2 cell,
-    # 4.2 MB at 4K, exactly the information of the dense field -- and rank 0 expands every gathered
-    # grid to the dense .flo field with the expand kernel (copy_to_all_pixels).
-    def device_view(ptr, shape, typestr):
-        class _View:
-            pass
-        v = _View()
-        v.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2, "strides": None}
-        return torch.as_tensor(v, device=torch.device("cuda", local_rank))
-
-    gather_list = flows = None
-    work_stream = None
+    # Multi-GPU (sequence.CellGather): each rank's result travels as the compact cell grid -- one int16 (dx, dy) pair
+    # per 2x2 cell, 4.2 MB at 4K, exactly the information of the dense field -- in one gather to rank 0, which expands
+    # every gathered grid to the dense .flo field (copy_to_all_pixels) on a second stream beside the next estimate.
+    gather = None
     if use_dist:
-        # an explicit stream: torch's default stream has handle 0, which bbme_set_stream reads as
-        # "create a private stream"
+        from blockbasedmotionestimation_amd.sequence import mf_cell_gather
+        # an explicit stream: torch's default stream has handle 0, which bbme_set_stream reads as "create a private stream"
         work_stream = torch.cuda.Stream(device=local_rank)
         torch.cuda.set_stream(work_stream)
-        assert work_stream.cuda_stream != 0
-        mf.set_stream(work_stream.cuda_stream)
-        cells_t = device_view(mf.cells_device_ptr(), (ph // 2, pw // 2), "<i4")     # packed int16 (dx, dy); NCCL has no int16
-        if rank == 0:
-            gather_list = [torch.empty_like(cells_t) for _ in range(world)]
-            flows = torch.empty((world, ph, pw, 2), dtype=torch.float32, device=cells_t.device)
-        # the gather of step i and rank 0's expansions run on a second stream, beside the estimate of step i + 1:
-        # the result is copied into one of two staging buffers on the work stream (4.2 MB), events order the rest
-        side_stream = torch.cuda.Stream(device=local_rank)
-        stage = [torch.empty_like(cells_t) for _ in range(2)]
-        ev_ready = [torch.cuda.Event() for _ in range(2)]
-        ev_free = [torch.cuda.Event() for _ in range(2)]
-    step_no = [0]
+        gather = mf_cell_gather(mf, local_rank)
 
     def step():
-        if not use_dist:
+        if gather is None:
             mf.estimate_async()                   # whole pyramid, no host wait
-            return
-        b = step_no[0] & 1
-        step_no[0] += 1
-        work_stream.wait_event(ev_free[b])        # the gather that read this staging buffer two steps ago is done
-        mf.estimate_async()
-        stage[b].copy_(cells_t)
-        ev_ready[b].record(work_stream)
-        with torch.cuda.stream(side_stream):
-            side_stream.wait_event(ev_ready[b])
-            dist.gather(stage[b], gather_list, dst=0)
-            if rank == 0:
-                for r in range(world):
-                    mf.expand_cells_device(gather_list[r].data_ptr(), flows[r].data_ptr(), side_stream.cuda_stream)
-            ev_free[b].record(side_stream)
+        else:
+            gather.step()
 
     def fence():
-        if use_dist:
-            side_stream.synchronize()
-            dist.barrier()
+        if gather is not None:
+            gather.fence()
         mf.synchronize()
         torch.cuda.synchronize()
 
@@ -217,7 +207,7 @@ def main():
     result_flow = mf.get_flow() if rank == 0 else None
     if use_dist and rank == 0:
         # the field rank 0 expanded from its own gathered cells must be the field its context holds
-        assert np.array_equal(flows[0].cpu().numpy(), result_flow), "gathered + expanded field differs"
+        assert np.array_equal(gather.flows[0].cpu().numpy(), result_flow), "gathered + expanded field differs"
 
     # a sequence on one GPU: K independent pairs in flight, one context (and private stream) each.
     # One pair leaves most of the chip idle while the regulariser walks its dependency chains, so
@@ -352,12 +342,18 @@ def main():
             out["host_boundary"] = host_boundary
         out["epe_vs_middlebury_gt"] = epe_on_ground_truth(bbme, local_rank)
         if not args.no_cpu_baseline:
-            dt, parity = cpu_baseline(f1, f2, search, block, levels, result_flow)
-            out["cpu_baseline"] = {"value": round(blocks[0] / dt / 1e6, 5), "unit": "Mblocks/s", "cores": 1,
-                                   "kind": "port", "seconds": round(dt, 2),
+            (dt1, _, par1), (dtn, threads, parn) = cpu_baseline(f1, f2, search, block, levels, result_flow)
+            model, nproc, usable = cpu_info()
+            out["cpu_baseline"] = {"value": round(blocks[0] / dt1 / 1e6, 5), "unit": "Mblocks/s", "cores": 1,
+                                   "kind": "port", "seconds": round(dt1, 2),
                                    "sample": "the same full %s pair, whole pyramid, oracle/bbme_oracle.c "
-                                             "(-O3 -march=native, 1 thread, no SAD cache)" % args.workload}
-            out["parity_vs_oracle"] = parity
+                                             "(-O3 -march=native, 1 thread like the reference, no SAD cache)" % args.workload,
+                                   "all_cores": {"value": round(blocks[0] / dtn / 1e6, 5), "unit": "Mblocks/s",
+                                                 "cores": threads, "seconds": round(dtn, 2),
+                                                 "note": "same pair; OpenMP over the macroblocks of the search "
+                                                         "(calcLevelBM), regulariser sweeps sequential"},
+                                   "host": {"cpu_model": model, "nproc": nproc, "usable_cores": usable}}
+            out["parity_vs_oracle"] = bool(par1 and parn)
         print(json.dumps(out))
     mf.close()
     if use_dist:

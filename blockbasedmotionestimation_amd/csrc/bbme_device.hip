@@ -11,6 +11,7 @@
 
 #include "bbme_internal.hpp"
 #include "bbme_kernels.hpp"
+#include "bbme_regtile.hpp"
 
 using namespace bbme;
 
@@ -55,12 +56,14 @@ struct bbme_ctx {
     std::vector<Level> lv;
     float *flow = nullptr;                        // dense padded H0 x W0 float2
     uint32_t *list[2] = {nullptr, nullptr};
-    uint8_t *flags[2] = {nullptr, nullptr};       // dirty flags of the regulariser, one byte per block, all zero between sweeps
-    int relax_steps = -1;                         // k_reg_iter launches per sweep; -1 = by grid size (BBME_RELAX_STEPS overrides)
+    uint32_t *marks = nullptr;                    // work list k_reg_tile leaves for k_reg_solve (block indices)
+    uint32_t mark_cap = 0;
+    int round_cap = 0;                            // > 0: test knob, the regulariser's waves give up after this many rounds
     uint32_t *own = nullptr;                      // ownership counters of the solver, one word per block
     uint32_t own_pitch = 0;                       // transposed layout: 32 residue classes of own_pitch words
-    uint32_t *counters = nullptr;                 // 8 words
+    uint32_t *counters = nullptr;                 // 64 words (RegArgs::counters)
     bool frames_set = false;
+    int solve_waves = 4;                          // waves per solver workgroup (1, 2 or 4); BBME_SOLVE_WAVES
     int solve_wgs = 256;                          // most workgroups of k_reg_solve (4 independent waves each): one wave per SIMD
     int xcd_remap = 1;                            // XCD-aware block order in k_search_fast; BBME_XCD_REMAP
     bool force_generic_search = false;            // BBME_GENERIC_SEARCH=1: use k_search_generic everywhere
@@ -90,6 +93,22 @@ int check_level(const bbme_ctx *c, int level)
 void drop_graph(bbme_ctx *c)
 {
     if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+}
+
+// The regulariser's waves leave at a round cap instead of spinning for ever (RegArgs::round_cap); a sweep that hit
+// it has not reached the fixed point and its field must not be handed out as a result.  Waits for the stream.  On
+// that path the solver's ownership words and counters are stale too: cleared, so that the context stays usable.
+int check_converged(bbme_ctx *c)
+{
+    uint32_t flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, c->counters + 5, sizeof flag, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!flag) return BBME_OK;
+    HIP_TRY(hipMemsetAsync(c->own, 0, (size_t)c->own_pitch * 32 * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(c->counters, 0, 256, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return bbme::fail(BBME_ERR_STATE, "a regulariser sweep hit its round cap without converging: the motion field is not "
+                                      "the reference's and has been discarded");
 }
 
 // ---- launches ---------------------------------------------------------------------------
@@ -169,28 +188,16 @@ int launch_search(bbme_ctx *c, int level)
 }
 
 template <int BS>
-void launch_sweep_t(RegArgs a, uint8_t *const flags[2], int relax_steps, int max_solve_wgs, hipStream_t s)
+void launch_sweep_t(RegArgs a, int max_solve_wgs, int solve_waves, hipStream_t s)
 {
-    constexpr int LPB = RegCfg<BS>::LPB;
+    constexpr int T = RegTile<BS>::T;
     const long long blocks = (long long)a.rows * a.cols;
-    const int grid1 = (int)((blocks * LPB + 255) / 256);
-    // every solver wave scans 16 blocks per step; more workgroups than that would find nothing
-    // a multiple of 8 workgroups: one share per XCD (k_reg_solve's bands)
-    const int grid2 = (int)((std::min<long long>(max_solve_wgs, (blocks + 63) / 64) + 7) / 8 * 8);
-    // pass 1 marks flags[0]; relaxation step i consumes flags[i & 1] and marks the other; the solver
-    // consumes what the last step marked.  Every flag is zero again afterwards.
-    a.flag_cur = nullptr; a.flag_next = flags[0];
-    hipLaunchKernelGGL(k_reg_pass1<BS>, dim3(grid1), dim3(256), 0, s, a);
-    int cur = 0;
-    for (int i = 0; i < relax_steps; ++i, cur ^= 1) {
-        a.flag_cur = flags[cur]; a.flag_next = flags[cur ^ 1];
-        constexpr int T = RegIter<BS>::T;
-        const unsigned tiles = (unsigned)(((a.cols + T - 1) / T) * ((a.rows + T - 1) / T));
-        hipLaunchKernelGGL(k_reg_iter<BS>, dim3(tiles), dim3(256), 0, s, a);
-    }
-    a.flag_cur = flags[cur]; a.flag_next = nullptr;
-    static const int solve_waves = getenv("BBME_SOLVE_WAVES") ? std::max(1, std::min(4, atoi(getenv("BBME_SOLVE_WAVES")))) : 4;
-    hipLaunchKernelGGL(k_reg_solve<BS>, dim3(grid2), dim3(64 * (solve_waves == 3 ? 4 : solve_waves)), 0, s, a);
+    const unsigned tiles = (unsigned)(((a.cols + T - 1) / T) * ((a.rows + T - 1) / T));
+    // k_reg_tile: pass 1 + every tile's local fixed point; leaves the blocks with a stale input from another tile
+    // on the work list.  k_reg_solve: finishes exactly from that list (every wave takes 16 entries per step).
+    hipLaunchKernelGGL(k_reg_tile<BS>, dim3(tiles), dim3(256), 0, s, a);
+    const int grid2 = (int)std::max<long long>(1, std::min<long long>(max_solve_wgs, (blocks + 63) / 64));
+    hipLaunchKernelGGL(k_reg_solve<BS>, dim3(grid2), dim3(64 * solve_waves), 0, s, a);
 }
 
 int launch_sweep(bbme_ctx *c, int level, int b, int mult)
@@ -218,34 +225,23 @@ int launch_sweep(bbme_ctx *c, int level, int b, int mult)
     a.list0 = c->list[0]; a.list1 = c->list[1];
     a.own = c->own;
     a.own_pitch = c->own_pitch;
-    static const int rounds_env = getenv("BBME_LOCAL_ROUNDS") ? atoi(getenv("BBME_LOCAL_ROUNDS")) : 8;
-    a.local_rounds = std::max(1, rounds_env);
+    a.mark_list = c->marks;
+    a.mark_count = c->counters + 16;
+    a.mark_cap = c->mark_cap;
     static const int wide_env = getenv("BBME_WIDE_THRESHOLD") ? atoi(getenv("BBME_WIDE_THRESHOLD")) : 4;
     a.wide_threshold = (uint32_t)std::max(4, wide_env);
+    // every round of a wave either empties part of its queue or follows a real change, and a change can only travel
+    // along the raster dependency chain (< 2 * rows + cols blocks): the cap is an exit every wave reaches even if
+    // that reasoning were wrong; hitting it raises counters[5] and the result is refused (BBME_ERR_STATE)
+    a.round_cap = c->round_cap > 0 ? (uint32_t)c->round_cap : 64u * (uint32_t)(2 * a.rows + a.cols + 16);
     a.counters = c->counters;
-    // relaxation launches (k_reg_iter, 8 local rounds per tile): one more launch (>= 5 us), which only the sweeps with
-    // heavy first generations repay -- measured on cfg3 / cfg4 / cfg2: large grids of small blocks, one launch per sweep
-    // (cfg4 -6 %, cfg2 -2 %, cfg3 neutral)
-    const long long nblk = (long long)a.rows * a.cols;
-    int steps = c->relax_steps;
-    if (steps < 0) {
-        // BBME_RELAX_RULE="min_blocks,max_b,steps_first,steps_second" (tuning knob)
-        static long long min_blocks = 100000;
-        static int max_b = 4, s1 = 1, s2 = 1;
-        static const bool parsed = [] {
-            if (const char *e = getenv("BBME_RELAX_RULE")) sscanf(e, "%lld,%d,%d,%d", &min_blocks, &max_b, &s1, &s2);
-            return true;
-        }();
-        (void)parsed;
-        steps = (nblk >= min_blocks && b <= max_b) ? (mult == 1 ? s1 : s2) : 0;
-    }
     switch (b) {
-    case 2:  launch_sweep_t<2>(a, c->flags, steps, c->solve_wgs, c->stream); break;
-    case 4:  launch_sweep_t<4>(a, c->flags, steps, c->solve_wgs, c->stream); break;
-    case 8:  launch_sweep_t<8>(a, c->flags, steps, c->solve_wgs, c->stream); break;
-    case 16: launch_sweep_t<16>(a, c->flags, steps, c->solve_wgs, c->stream); break;
-    case 32: launch_sweep_t<32>(a, c->flags, steps, c->solve_wgs, c->stream); break;
-    case 64: launch_sweep_t<64>(a, c->flags, steps, c->solve_wgs, c->stream); break;
+    case 2:  launch_sweep_t<2>(a, c->solve_wgs, c->solve_waves, c->stream); break;
+    case 4:  launch_sweep_t<4>(a, c->solve_wgs, c->solve_waves, c->stream); break;
+    case 8:  launch_sweep_t<8>(a, c->solve_wgs, c->solve_waves, c->stream); break;
+    case 16: launch_sweep_t<16>(a, c->solve_wgs, c->solve_waves, c->stream); break;
+    case 32: launch_sweep_t<32>(a, c->solve_wgs, c->solve_waves, c->stream); break;
+    case 64: launch_sweep_t<64>(a, c->solve_wgs, c->solve_waves, c->stream); break;
     default: return bbme::fail(BBME_ERR_UNSUPPORTED, "block size %d", b);
     }
     HIP_TRY(hipGetLastError());
@@ -352,7 +348,8 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
     bbme_ctx *c = new bbme_ctx();
     c->params = *params; c->geom = g; c->device = device;
     if (const char *e = getenv("BBME_SOLVE_WGS")) c->solve_wgs = std::max(1, std::min(8192, atoi(e)));
-    if (const char *e = getenv("BBME_RELAX_STEPS")) c->relax_steps = std::max(0, std::min(64, atoi(e)));
+    if (const char *e = getenv("BBME_SOLVE_WAVES")) { const int v = atoi(e); c->solve_waves = v <= 1 ? 1 : (v == 2 ? 2 : 4); }
+    if (const char *e = getenv("BBME_TEST_ROUND_CAP")) c->round_cap = std::max(0, atoi(e));
     if (const char *e = getenv("BBME_NO_GRAPH")) c->use_graph = atoi(e) == 0;
     if (const char *e = getenv("BBME_GENERIC_SEARCH")) c->force_generic_search = atoi(e) != 0;
     if (const char *e = getenv("BBME_XCD_REMAP")) c->xcd_remap = atoi(e) != 0;
@@ -383,7 +380,7 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
             (err = hipMemset(L.img1, 0, plane)) != hipSuccess || (err = hipMemset(L.img2, 0, plane)) != hipSuccess ||
             (err = hipMemcpy(L.spiral, packed.data(), packed.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
             return cleanup_fail(bbme::fail(BBME_ERR_HIP, "allocating level %d: %s", l, hipGetErrorString(err)));
-        if (L.block == 8 || L.block == 16 || (L.block == 32 && L.range <= 45)) {
+        if (L.block == 8 || L.block == 16 || L.block == 32) {
             // the strip kernel reads rank rows dy0 .. dy0+S-1 as 4 x u16 per column group
             SearchPlan plan = plan_search(L.range, L.block, L.block == 32 ? 8 : 16);
             L.fast = true;
@@ -404,19 +401,16 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
     // pitch = 33 (mod 64) words: consecutive blocks land 132 bytes (mod 256) apart
     c->own_pitch = (uint32_t)(((max_blocks + 31) / 32 + 63) / 64 * 64 + 33);
     const size_t bit_words = (size_t)c->own_pitch * 32;
+    c->mark_cap = (uint32_t)max_blocks;
     const size_t flow_bytes = (size_t)g.padded_width * g.padded_height * 2 * sizeof(float);
-    const size_t flag_bytes = (max_blocks + 2047) / 2048 * 2048 + 2048;       // k_reg_iter reads whole 2048-block chunks
     if ((err = hipMalloc(&c->flow, flow_bytes)) != hipSuccess ||
         (err = hipMalloc(&c->list[0], max_blocks * 4)) != hipSuccess ||
         (err = hipMalloc(&c->list[1], max_blocks * 4)) != hipSuccess ||
+        (err = hipMalloc(&c->marks, max_blocks * 4)) != hipSuccess ||     // <= 6T marks per tile of T*T blocks, T >= 8
         (err = hipMalloc(&c->own, bit_words * 4)) != hipSuccess ||
-        (err = hipMalloc(&c->flags[0], flag_bytes)) != hipSuccess ||
-        (err = hipMalloc(&c->flags[1], flag_bytes)) != hipSuccess ||
-        (err = hipMemset(c->flags[0], 0, flag_bytes)) != hipSuccess ||
-        (err = hipMemset(c->flags[1], 0, flag_bytes)) != hipSuccess ||
-        (err = hipMalloc(&c->counters, 64)) != hipSuccess ||
+        (err = hipMalloc(&c->counters, 256)) != hipSuccess ||
         (err = hipMemset(c->own, 0, bit_words * 4)) != hipSuccess ||
-        (err = hipMemset(c->counters, 0, 64)) != hipSuccess ||
+        (err = hipMemset(c->counters, 0, 256)) != hipSuccess ||
         (err = hipMemset(c->flow, 0, flow_bytes)) != hipSuccess)
         return cleanup_fail(bbme::fail(BBME_ERR_HIP, "allocating work buffers: %s", hipGetErrorString(err)));
     HIP_TRY(hipDeviceSynchronize());
@@ -439,7 +433,7 @@ int bbme_destroy(bbme_ctx *c)
     (void)hipFree(c->flow);
     (void)hipFree(c->list[0]); (void)hipFree(c->list[1]);
     (void)hipFree(c->own);
-    (void)hipFree(c->flags[0]); (void)hipFree(c->flags[1]);
+    (void)hipFree(c->marks);
     (void)hipFree(c->counters);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -597,8 +591,7 @@ int bbme_synchronize(bbme_ctx *c)
 {
     if (int rc = check_ctx(c)) return rc;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return BBME_OK;
+    return check_converged(c);
 }
 
 int bbme_flow_device(bbme_ctx *c, const float **d_flow)
@@ -616,8 +609,7 @@ int bbme_get_flow_host(bbme_ctx *c, float *flow)
     HIP_TRY(hipSetDevice(c->device));
     const size_t bytes = (size_t)c->geom.padded_width * c->geom.padded_height * 2 * sizeof(float);
     HIP_TRY(hipMemcpyAsync(flow, c->flow, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return BBME_OK;
+    return check_converged(c);
 }
 
 int bbme_get_cells_host(bbme_ctx *c, int16_t *cells)
@@ -629,8 +621,7 @@ int bbme_get_cells_host(bbme_ctx *c, int16_t *cells)
     HIP_TRY(hipSetDevice(c->device));
     const size_t n = (size_t)(L.width / 2) * (L.height / 2);
     HIP_TRY(hipMemcpyAsync(cells, L.grid[L.cur], n * sizeof(mv_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return BBME_OK;
+    return check_converged(c);
 }
 
 int bbme_cells_device(bbme_ctx *c, const int16_t **d_cells)
@@ -689,6 +680,7 @@ int bbme_calculate_mse_device(bbme_ctx *c, const float *d_gtruth, int gt_width, 
     if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
     (void)hipFree(d_sum);
     if (err != hipSuccess) return bbme::fail(BBME_ERR_HIP, "bbme_calculate_mse_device: %s", hipGetErrorString(err));
+    if (int rc = check_converged(c)) return rc;
     double error = 0;
     unsigned long long count = 0;
     for (int i = 0; i < groups; ++i) { error += h_sum[i]; count += h_cnt[i]; }
@@ -724,7 +716,7 @@ int bbme_stage_get_mvs(bbme_ctx *c, int level, int block, int16_t *mvs)
     const int rows = L.height / L.cur_block, cols = L.width / L.cur_block;
     std::vector<mv_t> host((size_t)rows * cols);
     HIP_TRY(hipMemcpyAsync(host.data(), L.grid[L.cur], host.size() * sizeof(mv_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc = check_converged(c)) return rc;
     // divide_blocks (:845-862) repeated: every finer block inherits its parent's MV
     const int f = L.cur_block / block, orows = rows * f, ocols = cols * f;
     for (int r = 0; r < orows; ++r)
@@ -766,7 +758,7 @@ int bbme_last_sweep_passes(bbme_ctx *c, int *passes)
     if (!passes) return bbme::fail(BBME_ERR_INVALID, "null output");
     HIP_TRY(hipSetDevice(c->device));
     uint32_t host[8];
-    HIP_TRY(hipMemcpyAsync(host, c->counters, sizeof host, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(host, c->counters + 32, sizeof host, hipMemcpyDeviceToHost, c->stream));   // as the last sweep left them
     HIP_TRY(hipStreamSynchronize(c->stream));
     passes[0] = (int)host[3];
     passes[1] = (int)host[4];
@@ -779,7 +771,7 @@ int bbme_sweep_stats(bbme_ctx *c, unsigned *stats)
     if (int rc = check_ctx(c)) return rc;
     if (!stats) return bbme::fail(BBME_ERR_INVALID, "null output");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemcpyAsync(stats, c->counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(stats, c->counters + 32, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return BBME_OK;
 }

@@ -11,12 +11,128 @@ import os
 import numpy as np
 
 
+def local_device():
+    """The GPU of this process: one process per GPU, LOCAL_RANK as torch.distributed.run exports it."""
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def cells_to_words(cells):
+    """(rows, cols, 2) int16 (dx, dy) per 2x2 cell -> (rows, cols) int32 words, dx in the low half: the layout of the
+    MV grids in HBM and the unit the gather moves (NCCL has no int16)."""
+    c = np.ascontiguousarray(cells, np.int16)
+    return c.view(np.int32).reshape(c.shape[0], c.shape[1])
+
+
+def flow_to_cells(flow_padded):
+    """The dense padded field -> its 2x2-cell grid (the field is constant on 2x2 cells, motion_framework.cpp:205-206)."""
+    return np.ascontiguousarray(flow_padded[::2, ::2]).astype(np.int16)
+
+
+def expand_cells_host(words):
+    """copy_to_all_pixels (motion_framework.cpp:815-826) on the host: (rows, cols) int32 words -> dense
+    (2*rows, 2*cols, 2) float32.  The CPU stand-in for bbme_expand_cells_device in the gloo tests."""
+    w = np.ascontiguousarray(words, np.int32)
+    mv = w.view(np.int16).reshape(w.shape[0], w.shape[1], 2).astype(np.float32)
+    return np.repeat(np.repeat(mv, 2, axis=0), 2, axis=1)
+
+
+class CellGather:
+    """The multi-GPU step of a sequence (BASELINE configs[4]): every rank estimates one pair per step, the
+    results travel as compact cell grids -- one packed int16 (dx, dy) pair per 2x2 cell, 16x smaller than the dense
+    field and exactly the same information -- in ONE gather to rank 0 (torch.distributed: "nccl" is RCCL over xGMI;
+    "gloo" in the CPU tests), and rank 0 expands every gathered grid to the dense .flo field.
+
+    estimate()                 enqueues this rank's estimate (GPU: on the current stream, no host wait; CPU: computes)
+    cells                      torch int32 tensor (rows, cols) the estimate leaves its result in
+    expand(words, flow, strm)  rank 0: one gathered grid -> dense (2*rows, 2*cols, 2) float32 tensor `flow`;
+                               strm = raw HIP stream handle the expansion must run on (None on the CPU)
+    On a GPU the gather of step i and rank 0's expansions run on a second stream beside the estimate of step i + 1:
+    each step copies its grid into one of two staging buffers; events order the two streams.  `flows` (rank 0) holds
+    the dense fields of the last finished step, one per rank.
+    """
+
+    def __init__(self, estimate, cells, expand, group=None, dst=0):
+        import torch
+        import torch.distributed as dist
+        self._dist, self._torch = dist, torch
+        self.estimate, self.cells, self.expand = estimate, cells, expand
+        self.group, self.dst = group, dst
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.on_gpu = cells.is_cuda
+        rows, cols = cells.shape
+        root = self.rank == dst
+        self.gather_list = [torch.empty_like(cells) for _ in range(self.world)] if root else None
+        self.flows = torch.empty((self.world, 2 * rows, 2 * cols, 2), dtype=torch.float32, device=cells.device) if root else None
+        self.stage = [torch.empty_like(cells) for _ in range(2)]
+        self.steps = 0
+        if self.on_gpu:
+            self.work_stream = torch.cuda.current_stream(cells.device)
+            self.side_stream = torch.cuda.Stream(device=cells.device)
+            self.ev_ready = [torch.cuda.Event() for _ in range(2)]
+            self.ev_free = [torch.cuda.Event() for _ in range(2)]
+
+    def step(self):
+        dist, torch = self._dist, self._torch
+        b = self.steps & 1
+        self.steps += 1
+        if not self.on_gpu:
+            self.estimate()
+            self.stage[b].copy_(self.cells)
+            dist.gather(self.stage[b], self.gather_list, dst=self.dst, group=self.group)
+            if self.rank == self.dst:
+                for r in range(self.world):
+                    self.expand(self.gather_list[r], self.flows[r], None)
+            return
+        self.work_stream.wait_event(self.ev_free[b])      # the gather that read this staging buffer two steps ago is done
+        self.estimate()
+        with torch.cuda.stream(self.work_stream):
+            self.stage[b].copy_(self.cells)
+        self.ev_ready[b].record(self.work_stream)
+        with torch.cuda.stream(self.side_stream):
+            self.side_stream.wait_event(self.ev_ready[b])
+            dist.gather(self.stage[b], self.gather_list, dst=self.dst, group=self.group)
+            if self.rank == self.dst:
+                for r in range(self.world):
+                    self.expand(self.gather_list[r], self.flows[r], self.side_stream.cuda_stream)
+            self.ev_free[b].record(self.side_stream)
+
+    def fence(self):
+        """Both streams idle on every rank."""
+        if self.on_gpu:
+            self.side_stream.synchronize()
+            self.work_stream.synchronize()
+        self._dist.barrier(group=self.group)
+
+
+def mf_cell_gather(mf, device, group=None):
+    """CellGather over a context (MF) whose frames are set: the estimate, the context's cell grid and
+    bbme_expand_cells_device_on.  The context is moved onto torch's current stream, which must not be the default
+    stream (handle 0 means "private stream" to bbme_set_stream)."""
+    import torch
+    stream = torch.cuda.current_stream(device)
+    if stream.cuda_stream == 0:
+        raise ValueError("mf_cell_gather: run under an explicit torch.cuda.Stream (the default stream has handle 0)")
+    mf.set_stream(stream.cuda_stream)
+
+    class _View:
+        pass
+    v = _View()
+    v.__cuda_array_interface__ = {"shape": (mf.padded_height // 2, mf.padded_width // 2), "typestr": "<i4",
+                                  "data": (mf.cells_device_ptr(), False), "version": 2, "strides": None}
+    cells = torch.as_tensor(v, device=torch.device("cuda", device))
+
+    def expand(words, flow, strm):
+        mf.expand_cells_device(words.data_ptr(), flow.data_ptr(), strm)
+    return CellGather(mf.estimate_async, cells, expand, group=group)
+
+
 def shard_pairs(n_pairs, rank, world_size):
     """Global indices of the pairs rank `rank` computes."""
     return list(range(rank, n_pairs, world_size))
 
 
-def estimate_pairs_pipelined(pairs, search_size, block_size, device=0, in_flight=4):
+def estimate_pairs_pipelined(pairs, search_size, block_size, device=None, in_flight=4):
     """All pairs of `pairs` (a list of (frame1, frame2), equal sizes) on ONE GPU, `in_flight` of them at a time.
 
     One context per slot, created once (level state, launch graph) and re-used round-robin; every
@@ -29,6 +145,8 @@ def estimate_pairs_pipelined(pairs, search_size, block_size, device=0, in_flight
     from .motion_framework import MF
     if not pairs:
         return []
+    if device is None:
+        device = local_device()
     slots = []
     out = [None] * len(pairs)
     pending = []                                           # (slot, pair index), oldest first
@@ -75,7 +193,7 @@ def _gpu_compute(search_size, block_size, device):
 
 
 def estimate_sequence(pairs, search_size, block_size, n_pairs=None, out_dir=None, compute=None,
-                      device=0, group=None):
+                      device=None, group=None):
     """Run the local shard and gather every pair's (H, W, 2) float32 field on rank 0.
 
     pairs    : dict {global_pair_index: (frame1, frame2)} holding at least this rank's shard
@@ -90,6 +208,8 @@ def estimate_sequence(pairs, search_size, block_size, n_pairs=None, out_dir=None
     world = dist.get_world_size(group) if distributed else 1
     if n_pairs is None:
         n_pairs = max(pairs) + 1
+    if device is None:
+        device = local_device()                           # one process per GPU: never every rank on cuda:0
     if compute is None:
         compute = _gpu_compute(search_size, block_size, device)
     mine = shard_pairs(n_pairs, rank, world)

@@ -394,6 +394,12 @@ void orc_calc_level_bm(orc_mf *mf, int level)
 {
     orc_level *lv = &mf->lv[level];
     int bs = lv->block_size;
+    /* Blocks are independent in calcLevelBM (each reads and writes only its own origin cell), so the all-cores leg of
+     * bench.py's cpu_baseline builds this file with -fopenmp; without it the pragma is ignored and the loop is the
+     * reference's single thread.  The regulariser sweeps stay sequential (they are order dependent). */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
     for (int i = 0; i < lv->height; i += bs)
         for (int j = 0; j < lv->width; j += bs) {
             float *f = FLOW_AT(lv, i, j);

@@ -16,10 +16,10 @@ for r in rows[a:b]:
     if 'search' in n:
         if line: print(' '.join(line))
         line = ['search %6.1f |' % d]; tot['search'] += d
-    elif 'pass1' in n: tot['pass1'] += d; p1 = d; it = 0.0
+    elif 'k_reg_tile' in n: tot['pass1'] += d; p1 = d; it = 0.0
     elif 'k_reg_iter' in n: tot['iter'] += d; it += d
     elif 'solve' in n:
         tot['solve'] += d
         line.append(('%5.1f+%5.1f' % (p1, d)) if it == 0.0 else ('%5.1f+[%.1f]+%5.1f' % (p1, it, d)))
 print(' '.join(line))
-print('total %.1f us: search %.1f pass1 %.1f relax %.1f solve %.1f' % ((int(rows[b-1]['End_Timestamp']) - int(rows[a]['Start_Timestamp'])) / 1e3, tot['search'], tot['pass1'], tot['iter'], tot['solve']))
+print('total %.1f us: search %.1f tile %.1f relax %.1f solve %.1f' % ((int(rows[b-1]['End_Timestamp']) - int(rows[a]['Start_Timestamp'])) / 1e3, tot['search'], tot['pass1'], tot['iter'], tot['solve']))

@@ -74,3 +74,71 @@ def test_single_process_sequence(bbme, oracle):
         return np.zeros(f1.shape + (2,), np.float32)
     res = estimate_sequence(pairs, [30], [16], compute=compute)
     assert len(res) == 3 and len(calls) == 3
+
+
+def _cell_worker(rank, world, port, out_dir, steps):
+    """One rank of the bench's multi-GPU step (sequence.CellGather), CPU edition: the oracle stands in for this rank's
+    HIP estimate, expand_cells_host for the expand kernel; staging buffers, the gather and the root's expansion loop
+    are the product code bench.py runs on N GPUs."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from blockbasedmotionestimation_amd.sequence import CellGather, cells_to_words, expand_cells_host, flow_to_cells
+    from blockbasedmotionestimation_amd.synth import synth_pair
+    from oracle import bbme_oracle as O
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    search, block = [30, 30], [16, 16]
+    pw, ph = 160, 96                                      # no padding needed
+    cells = torch.zeros((ph // 2, pw // 2), dtype=torch.int32)
+    step_no = [0]
+
+    def estimate():                                       # a different pair every step: stale buffers would show
+        f1, f2, _ = synth_pair(pw, ph, 700 + 10 * step_no[0] + rank, max_motion=6)
+        step_no[0] += 1
+        omf = O.OracleMF(f1, f2, search, block)
+        cells.copy_(torch.from_numpy(cells_to_words(flow_to_cells(omf.calc_motion_block_matching()))))
+        omf.close()
+
+    def expand(words, flow, stream):
+        assert stream is None
+        flow.copy_(torch.from_numpy(expand_cells_host(words.numpy())))
+
+    g = CellGather(estimate, cells, expand)
+    assert (g.flows is not None) == (rank == 0)
+    for _ in range(steps):
+        g.step()
+    g.fence()
+    if rank == 0:
+        np.save(os.path.join(out_dir, "flows.npy"), g.flows.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("steps", [1, 3])
+def test_two_rank_cell_gather(tmp_path, oracle, bbme, steps):
+    """configs[4]'s step with world size 2: after `steps` steps rank 0 holds, per rank, the dense field of that rank's
+    LAST pair (both staging buffers have been used when steps >= 2)."""
+    import torch.multiprocessing as mp
+    out_dir = str(tmp_path)
+    mp.spawn(_cell_worker, args=(2, _free_port(), out_dir, steps), nprocs=2, join=True)
+    got = np.load(os.path.join(out_dir, "flows.npy"))
+    assert got.shape == (2, 96, 160, 2)
+    for r in range(2):
+        f1, f2, _ = bbme.synth_pair(160, 96, 700 + 10 * (steps - 1) + r, max_motion=6)
+        omf = oracle.OracleMF(f1, f2, [30, 30], [16, 16])
+        assert np.array_equal(got[r], omf.calc_motion_block_matching()), "rank %d" % r
+        omf.close()
+
+
+def test_cell_words_round_trip():
+    from blockbasedmotionestimation_amd.sequence import cells_to_words, expand_cells_host, flow_to_cells
+    rng = np.random.default_rng(3)
+    cells = rng.integers(-480, 481, (5, 7, 2)).astype(np.int16)
+    dense = np.repeat(np.repeat(cells.astype(np.float32), 2, axis=0), 2, axis=1)
+    assert np.array_equal(flow_to_cells(dense), cells)
+    words = cells_to_words(cells)
+    assert words.dtype == np.int32 and words.shape == (5, 7)
+    assert np.array_equal(words & 0xffff, cells[..., 0].astype(np.int32) & 0xffff)      # dx in the low half
+    assert np.array_equal(expand_cells_host(words), dense)

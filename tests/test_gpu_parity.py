@@ -38,6 +38,13 @@ CASES = [
     (250, 130, [30], [16], 1015, 5),                            # odd-looking size, padded both ways (256 x 144)
     (1024, 64, [48, 48], [16, 16], 1016, 12),                   # two block rows at the coarse level, very wide
     (64, 1024, [48, 48], [16, 16], 1017, 12),                   # two block columns, very tall
+    # wide ranges: the fast kernel's packed (SAD, rank) keys at their limits (B=32: ranks up to 16128 need 14 bits)
+    (512, 384, [120], [32], 1018, 40),                          # B=32, R=44
+    (512, 384, [122], [32], 1019, 44),                          # B=32, R=45: 8281 candidates > 2^13
+    (512, 384, [123], [32], 1020, 44),                          # B=32, odd shift, R=45
+    (384, 384, [158], [32], 1021, 60),                          # B=32, R=63 (largest supported)
+    (384, 256, [134], [8], 1022, 60),                           # B=8, R=63
+    (384, 256, [142], [16], 1023, 60),                          # B=16, R=63
 ]
 
 
@@ -127,20 +134,47 @@ def test_random_configurations_twice(bbme, oracle, seed):
     mf.close()
     assert np.array_equal(a, exp), "first run differs from the oracle: %s %s %s" % (f1.shape, search, blocks)
     assert np.array_equal(b, exp), "second run differs from the oracle"
-    # the chip-wide relaxation steps before the solver (by default only on grids of >= 100 000 blocks) forced on:
-    # any number of them must leave the result untouched
+    # the split of the work between the tile kernel's local fixed point and the solver, and the number of solver
+    # waves, are pure scheduling: a solver of one workgroup of one wave must leave the same field
     import os
-    for steps in ("1", "3"):
-        os.environ["BBME_RELAX_STEPS"] = steps
-        try:
-            mf = bbme.MF(f1, f2, search, blocks, L)
-        finally:
-            del os.environ["BBME_RELAX_STEPS"]
-        for lvl in range(L):
-            mf.set_level_planes(lvl, omf.image(lvl, 1), omf.image(lvl, 2))
-        c = mf.calcMotionBlockMatching()
-        mf.close()
-        assert np.array_equal(c, exp), "%s relaxation steps per sweep change the field" % steps
+    os.environ["BBME_SOLVE_WGS"], os.environ["BBME_SOLVE_WAVES"] = "1", "1"
+    try:
+        mf = bbme.MF(f1, f2, search, blocks, L)
+    finally:
+        del os.environ["BBME_SOLVE_WGS"], os.environ["BBME_SOLVE_WAVES"]
+    for lvl in range(L):
+        mf.set_level_planes(lvl, omf.image(lvl, 1), omf.image(lvl, 2))
+    c = mf.calcMotionBlockMatching()
+    mf.close()
+    assert np.array_equal(c, exp), "a one-wave solver changes the field"
+
+
+def test_non_convergence_is_an_error(bbme):
+    """The regulariser's waves leave at a round cap instead of spinning for ever.  A sweep that hit the cap has not
+    reached the reference's field: every call that hands out a result must fail loudly (BBME_ERR_STATE), and the
+    context must work again afterwards.  The cap is forced to one round with a test knob."""
+    import os
+    from blockbasedmotionestimation_amd import _capi
+    f1, f2, _ = bbme.synth_pair(512, 384, 77, max_motion=20)
+    search, block = [48, 48], [16, 16]
+    ref = bbme.MF(f1, f2, search, block, 2)
+    expect = ref.calcMotionBlockMatching()
+    ref.close()
+    os.environ["BBME_TEST_ROUND_CAP"] = "1"
+    try:
+        mf = bbme.MF(f1, f2, search, block, 2)
+    finally:
+        del os.environ["BBME_TEST_ROUND_CAP"]
+    for call in (mf.calcMotionBlockMatching, lambda: (mf.estimate_async(), mf.synchronize()),
+                 lambda: (mf.estimate_async(), mf.get_cells())):
+        with pytest.raises(_capi.BbmeError) as err:
+            call()
+        assert err.value.status == _capi.ERR_STATE and "converg" in err.value.message
+    mf.close()
+    # an unconstrained context is unaffected
+    ok = bbme.MF(f1, f2, search, block, 2)
+    assert np.array_equal(ok.calcMotionBlockMatching(), expect)
+    ok.close()
 
 
 def test_flat_and_zero_frames_tie_breaking(bbme, oracle):
@@ -174,10 +208,11 @@ def test_large_motion_predictions_leave_image(bbme, oracle):
     compare_stagewise(bbme, oracle, f1, f2, [80, 80, 80], [16, 16, 16])
 
 
-def test_stagewise_parity_with_relaxation_steps(bbme, oracle, monkeypatch):
-    """Every intermediate MV grid with two relaxation steps forced into every sweep (k_reg_iter), on content
-    with many changes per sweep."""
-    monkeypatch.setenv("BBME_RELAX_STEPS", "2")
+def test_stagewise_parity_with_a_one_wave_solver(bbme, oracle, monkeypatch):
+    """Every intermediate MV grid when the solver behind the tile kernel is a single wave (the other extreme of the
+    schedule: every cross-tile chain is walked sequentially), on content with many changes per sweep."""
+    monkeypatch.setenv("BBME_SOLVE_WGS", "1")
+    monkeypatch.setenv("BBME_SOLVE_WAVES", "1")
     f1, f2, _ = bbme.synth_pair(328, 200, 5151, max_motion=12)
     compare_stagewise(bbme, oracle, f1, f2, [48, 48, 48], [16, 16, 16])
     rng = np.random.default_rng(12)
@@ -361,7 +396,7 @@ def test_errors_through_the_boundary(bbme):
 
 def test_1080p_pair_against_oracle(bbme, oracle):
     """BASELINE configs[1] at full size (1920x1080, 16x16, +-16, 3 levels) against the oracle, a few seconds of CPU:
-    large enough (130 560 / 522 240 blocks at b = 4 / 2) for the default schedule to include relaxation steps."""
+    130 560 / 522 240 blocks at b = 4 / 2: hundreds of tiles per sweep, work lists of thousands of blocks."""
     f1, f2, _ = bbme.synth_pair(1920, 1080, 1020, max_motion=12)
     search, block = [48] * 3, [16] * 3
     omf = oracle.OracleMF(f1, f2, search, block, use_cache=False)
@@ -376,8 +411,8 @@ def test_1080p_pair_against_oracle(bbme, oracle):
 
 def test_4k_uncorrelated_frames_against_oracle(bbme, oracle):
     """BASELINE configs[2] geometry (4K, 16x16, +-32, 4 levels) on the worst content for the regulariser: two
-    unrelated noise frames, so that nearly every block changes in nearly every sweep (long queues, relaxation
-    launches, overflow list).  The oracle needs a few seconds here because its searches hit the image border early."""
+    unrelated noise frames, so that nearly every block changes in nearly every sweep (long queues, full work
+    lists, overflow list).  The oracle needs a few seconds here because its searches hit the image border early."""
     rng = np.random.default_rng(5)
     f1 = rng.integers(0, 256, (2160, 3840), dtype=np.uint8)
     f2 = rng.integers(0, 256, (2160, 3840), dtype=np.uint8)
@@ -446,3 +481,39 @@ def test_full_size_properties(bbme, cfg):
     frac = np.mean((inner[..., 0] == dx) & (inner[..., 1] == dy))
     assert frac == 1.0, "only %.4f of interior pixels carry the true translation" % frac
     mf.close()
+
+
+def test_cell_gather_world_size_one_nccl(bbme, oracle):
+    """The multi-GPU step (sequence.CellGather / mf_cell_gather, what `bench.py --gpus N` runs) on the one GPU of this
+    box with an RCCL process group of size one: estimate on the work stream, cell grid staged, gathered and expanded
+    with the expand kernel on the side stream.  Three steps (both staging buffers, overlap of gather and next
+    estimate); rank 0's dense field must be the oracle's."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from blockbasedmotionestimation_amd.sequence import mf_cell_gather
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    f1, f2, _ = bbme.synth_pair(640, 360, 6100, max_motion=14)
+    search, block = [48, 48, 48], [16, 16, 16]
+    omf = oracle.OracleMF(f1, f2, search, block)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        mf = bbme.MF(f1, f2, search, block, 3)
+        for lvl in range(3):
+            mf.set_level_planes(lvl, omf.image(lvl, 1), omf.image(lvl, 2))
+        exp = omf.calc_motion_block_matching()
+        with torch.cuda.stream(torch.cuda.Stream(device=0)):
+            g = mf_cell_gather(mf, 0)
+            for _ in range(3):
+                g.step()
+            g.fence()
+            got = g.flows[0].cpu().numpy()
+        assert g.world == 1 and got.shape == exp.shape
+        assert np.array_equal(got, exp)
+        assert np.array_equal(mf.get_flow(), exp)
+        mf.close()
+    finally:
+        dist.destroy_process_group()
+        omf.close()
