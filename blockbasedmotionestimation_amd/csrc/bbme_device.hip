@@ -11,7 +11,6 @@
 
 #include "bbme_internal.hpp"
 #include "bbme_kernels.hpp"
-#include "bbme_regtile.hpp"
 
 using namespace bbme;
 
@@ -56,8 +55,9 @@ struct bbme_ctx {
     std::vector<Level> lv;
     float *flow = nullptr;                        // dense padded H0 x W0 float2
     uint32_t *list[2] = {nullptr, nullptr};
-    uint32_t *marks = nullptr;                    // work list k_reg_tile leaves for k_reg_solve (block indices)
-    uint32_t mark_cap = 0;
+    uint8_t *flags[2] = {nullptr, nullptr};       // dirty flags of the regulariser, one byte per block, all zero between sweeps
+    size_t flag_bytes = 0;
+    int relax_steps = -1;                         // k_reg_iter launches per sweep; -1 = by grid size (BBME_RELAX_STEPS overrides)
     int round_cap = 0;                            // > 0: test knob, the regulariser's waves give up after this many rounds
     uint32_t *own = nullptr;                      // ownership counters of the solver, one word per block
     uint32_t own_pitch = 0;                       // transposed layout: 32 residue classes of own_pitch words
@@ -106,6 +106,8 @@ int check_converged(bbme_ctx *c)
     if (!flag) return BBME_OK;
     HIP_TRY(hipMemsetAsync(c->own, 0, (size_t)c->own_pitch * 32 * 4, c->stream));
     HIP_TRY(hipMemsetAsync(c->counters, 0, 256, c->stream));
+    HIP_TRY(hipMemsetAsync(c->flags[0], 0, c->flag_bytes, c->stream));
+    HIP_TRY(hipMemsetAsync(c->flags[1], 0, c->flag_bytes, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return bbme::fail(BBME_ERR_STATE, "a regulariser sweep hit its round cap without converging: the motion field is not "
                                       "the reference's and has been discarded");
@@ -188,15 +190,25 @@ int launch_search(bbme_ctx *c, int level)
 }
 
 template <int BS>
-void launch_sweep_t(RegArgs a, int max_solve_wgs, int solve_waves, hipStream_t s)
+void launch_sweep_t(RegArgs a, uint8_t *const flags[2], int relax_steps, int max_solve_wgs, int solve_waves, hipStream_t s)
 {
-    constexpr int T = RegTile<BS>::T;
+    constexpr int LPB = RegCfg<BS>::LPB;
     const long long blocks = (long long)a.rows * a.cols;
-    const unsigned tiles = (unsigned)(((a.cols + T - 1) / T) * ((a.rows + T - 1) / T));
-    // k_reg_tile: pass 1 + every tile's local fixed point; leaves the blocks with a stale input from another tile
-    // on the work list.  k_reg_solve: finishes exactly from that list (every wave takes 16 entries per step).
-    hipLaunchKernelGGL(k_reg_tile<BS>, dim3(tiles), dim3(256), 0, s, a);
-    const int grid2 = (int)std::max<long long>(1, std::min<long long>(max_solve_wgs, (blocks + 63) / 64));
+    const int grid1 = (int)((blocks * LPB + 255) / 256);
+    // a multiple of 8 workgroups: one share per XCD (k_reg_solve's bands)
+    const int grid2 = (int)((std::min<long long>(max_solve_wgs, (blocks + 63) / 64) + 7) / 8 * 8);
+    // pass 1 marks flags[0]; relaxation step i consumes flags[i & 1] and marks the other; the solver
+    // consumes what the last step marked.  Every flag is zero again afterwards.
+    a.flag_cur = nullptr; a.flag_next = flags[0];
+    hipLaunchKernelGGL(k_reg_pass1<BS>, dim3(grid1), dim3(256), 0, s, a);
+    int cur = 0;
+    for (int i = 0; i < relax_steps; ++i, cur ^= 1) {
+        a.flag_cur = flags[cur]; a.flag_next = flags[cur ^ 1];
+        constexpr int T = RegIter<BS>::T;
+        const unsigned tiles = (unsigned)(((a.cols + T - 1) / T) * ((a.rows + T - 1) / T));
+        hipLaunchKernelGGL(k_reg_iter<BS>, dim3(tiles), dim3(256), 0, s, a);
+    }
+    a.flag_cur = flags[cur]; a.flag_next = nullptr;
     hipLaunchKernelGGL(k_reg_solve<BS>, dim3(grid2), dim3(64 * solve_waves), 0, s, a);
 }
 
@@ -225,9 +237,8 @@ int launch_sweep(bbme_ctx *c, int level, int b, int mult)
     a.list0 = c->list[0]; a.list1 = c->list[1];
     a.own = c->own;
     a.own_pitch = c->own_pitch;
-    a.mark_list = c->marks;
-    a.mark_count = c->counters + 16;
-    a.mark_cap = c->mark_cap;
+    static const int rounds_env = getenv("BBME_LOCAL_ROUNDS") ? atoi(getenv("BBME_LOCAL_ROUNDS")) : 8;
+    a.local_rounds = std::max(1, rounds_env);
     static const int wide_env = getenv("BBME_WIDE_THRESHOLD") ? atoi(getenv("BBME_WIDE_THRESHOLD")) : 4;
     a.wide_threshold = (uint32_t)std::max(4, wide_env);
     // every round of a wave either empties part of its queue or follows a real change, and a change can only travel
@@ -235,13 +246,28 @@ int launch_sweep(bbme_ctx *c, int level, int b, int mult)
     // that reasoning were wrong; hitting it raises counters[5] and the result is refused (BBME_ERR_STATE)
     a.round_cap = c->round_cap > 0 ? (uint32_t)c->round_cap : 64u * (uint32_t)(2 * a.rows + a.cols + 16);
     a.counters = c->counters;
+    // relaxation launches (k_reg_iter, 8 local rounds per tile): one more launch (>= 5 us), which only the sweeps with
+    // heavy first generations repay -- measured on cfg3 / cfg4 / cfg2: large grids of small blocks, one launch per sweep
+    const long long nblk = (long long)a.rows * a.cols;
+    int steps = c->relax_steps;
+    if (steps < 0) {
+        // BBME_RELAX_RULE="min_blocks,max_b,steps_first,steps_second" (tuning knob)
+        static long long min_blocks = 100000;
+        static int max_b = 4, s1 = 1, s2 = 1;
+        static const bool parsed = [] {
+            if (const char *e = getenv("BBME_RELAX_RULE")) sscanf(e, "%lld,%d,%d,%d", &min_blocks, &max_b, &s1, &s2);
+            return true;
+        }();
+        (void)parsed;
+        steps = (nblk >= min_blocks && b <= max_b) ? (mult == 1 ? s1 : s2) : 0;
+    }
     switch (b) {
-    case 2:  launch_sweep_t<2>(a, c->solve_wgs, c->solve_waves, c->stream); break;
-    case 4:  launch_sweep_t<4>(a, c->solve_wgs, c->solve_waves, c->stream); break;
-    case 8:  launch_sweep_t<8>(a, c->solve_wgs, c->solve_waves, c->stream); break;
-    case 16: launch_sweep_t<16>(a, c->solve_wgs, c->solve_waves, c->stream); break;
-    case 32: launch_sweep_t<32>(a, c->solve_wgs, c->solve_waves, c->stream); break;
-    case 64: launch_sweep_t<64>(a, c->solve_wgs, c->solve_waves, c->stream); break;
+    case 2:  launch_sweep_t<2>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->stream); break;
+    case 4:  launch_sweep_t<4>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->stream); break;
+    case 8:  launch_sweep_t<8>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->stream); break;
+    case 16: launch_sweep_t<16>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->stream); break;
+    case 32: launch_sweep_t<32>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->stream); break;
+    case 64: launch_sweep_t<64>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->stream); break;
     default: return bbme::fail(BBME_ERR_UNSUPPORTED, "block size %d", b);
     }
     HIP_TRY(hipGetLastError());
@@ -348,6 +374,7 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
     bbme_ctx *c = new bbme_ctx();
     c->params = *params; c->geom = g; c->device = device;
     if (const char *e = getenv("BBME_SOLVE_WGS")) c->solve_wgs = std::max(1, std::min(8192, atoi(e)));
+    if (const char *e = getenv("BBME_RELAX_STEPS")) c->relax_steps = std::max(0, std::min(64, atoi(e)));
     if (const char *e = getenv("BBME_SOLVE_WAVES")) { const int v = atoi(e); c->solve_waves = v <= 1 ? 1 : (v == 2 ? 2 : 4); }
     if (const char *e = getenv("BBME_TEST_ROUND_CAP")) c->round_cap = std::max(0, atoi(e));
     if (const char *e = getenv("BBME_NO_GRAPH")) c->use_graph = atoi(e) == 0;
@@ -401,12 +428,15 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
     // pitch = 33 (mod 64) words: consecutive blocks land 132 bytes (mod 256) apart
     c->own_pitch = (uint32_t)(((max_blocks + 31) / 32 + 63) / 64 * 64 + 33);
     const size_t bit_words = (size_t)c->own_pitch * 32;
-    c->mark_cap = (uint32_t)max_blocks;
+    c->flag_bytes = (max_blocks + 2047) / 2048 * 2048 + 2048;             // whole 16-flag segments (k_reg_solve), zero beyond the grid
     const size_t flow_bytes = (size_t)g.padded_width * g.padded_height * 2 * sizeof(float);
     if ((err = hipMalloc(&c->flow, flow_bytes)) != hipSuccess ||
         (err = hipMalloc(&c->list[0], max_blocks * 4)) != hipSuccess ||
         (err = hipMalloc(&c->list[1], max_blocks * 4)) != hipSuccess ||
-        (err = hipMalloc(&c->marks, max_blocks * 4)) != hipSuccess ||     // <= 6T marks per tile of T*T blocks, T >= 8
+        (err = hipMalloc(&c->flags[0], c->flag_bytes)) != hipSuccess ||
+        (err = hipMalloc(&c->flags[1], c->flag_bytes)) != hipSuccess ||
+        (err = hipMemset(c->flags[0], 0, c->flag_bytes)) != hipSuccess ||
+        (err = hipMemset(c->flags[1], 0, c->flag_bytes)) != hipSuccess ||
         (err = hipMalloc(&c->own, bit_words * 4)) != hipSuccess ||
         (err = hipMalloc(&c->counters, 256)) != hipSuccess ||
         (err = hipMemset(c->own, 0, bit_words * 4)) != hipSuccess ||
@@ -433,7 +463,7 @@ int bbme_destroy(bbme_ctx *c)
     (void)hipFree(c->flow);
     (void)hipFree(c->list[0]); (void)hipFree(c->list[1]);
     (void)hipFree(c->own);
-    (void)hipFree(c->marks);
+    (void)hipFree(c->flags[0]); (void)hipFree(c->flags[1]);
     (void)hipFree(c->counters);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -758,7 +788,7 @@ int bbme_last_sweep_passes(bbme_ctx *c, int *passes)
     if (!passes) return bbme::fail(BBME_ERR_INVALID, "null output");
     HIP_TRY(hipSetDevice(c->device));
     uint32_t host[8];
-    HIP_TRY(hipMemcpyAsync(host, c->counters + 32, sizeof host, hipMemcpyDeviceToHost, c->stream));   // as the last sweep left them
+    HIP_TRY(hipMemcpyAsync(host, c->counters, sizeof host, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     passes[0] = (int)host[3];
     passes[1] = (int)host[4];
@@ -771,7 +801,7 @@ int bbme_sweep_stats(bbme_ctx *c, unsigned *stats)
     if (int rc = check_ctx(c)) return rc;
     if (!stats) return bbme::fail(BBME_ERR_INVALID, "null output");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemcpyAsync(stats, c->counters + 32, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(stats, c->counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return BBME_OK;
 }

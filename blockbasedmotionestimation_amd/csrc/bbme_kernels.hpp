@@ -405,16 +405,15 @@ struct RegArgs {
     uint32_t *list0, *list1;    // overflow lists of the solver (block indices)
     uint32_t *own;              // ownership counters, one word per block (see "work-list state" below)
     uint32_t own_pitch;         // words per residue class of the transposed layout (own_slot)
-    // the blocks k_reg_tile found to have a stale input outside their tile: the solver's initial work
-    uint32_t *mark_list;
-    uint32_t *mark_count;       // = counters + 16
-    uint32_t mark_cap;          // capacity of mark_list
+    // dirty flags, one byte per block: a kernel consumes (and zeroes) flag_cur and marks flag_next.  A block is
+    // marked when one of its already-updated inputs (L, UL, UR, U) has just been changed.
+    uint8_t *flag_cur, *flag_next;
+    int local_rounds;           // k_reg_iter: rounds a workgroup runs on its tile within one launch
     uint32_t wide_threshold;    // solver: queue length above which a round uses the throughput form
     uint32_t round_cap;         // most rounds / idle spins of one wave before it gives up and raises counters[5]
     uint32_t *counters;         // [0..2] overflow list lengths (rotating), [3] safety-net passes, [4] blocks re-evaluated,
                                 // [5] sticky: a sweep hit a cap without converging, [6] solver ticket, [7] most rounds of
-                                // one wave, [8] rounds summed, [9..15] phase profile, [16] length of mark_list,
-                                // [32..47] copy of [0..15] as the last finished sweep left them (diagnostics)
+                                // one wave, [8] rounds summed, [9..15] phase profile
 };
 
 template <int BS> struct RegCfg {
@@ -728,6 +727,158 @@ __device__ __forceinline__ uint32_t own_release(const RegArgs &a, uint32_t x)  /
 }
 #define BBME_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
+// block (r, c) has a new estimate: its dependants R, DR, D, DL must be looked at again (idempotent byte stores)
+__device__ __forceinline__ void mark_dependants(const RegArgs &a, uint8_t *flags, int r, int c)
+{
+    const int dr[4] = {0, 1, 1, 1}, dc[4] = {1, 1, 0, -1};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int rr = r + dr[d], cc = c + dc[d];
+        if (rr < a.rows && cc >= 0 && cc < a.cols) flags[(size_t)rr * a.cols + cc] = 1;
+    }
+}
+
+template <int BS>
+__global__ __launch_bounds__(256) void k_reg_pass1(RegArgs a)
+{
+    constexpr int LPB = RegCfg<BS>::LPB;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    // the solver's counters (nothing else touches them before this sweep's solver launch)
+    if (t < 16 && t != 5) a.counters[t] = 0;
+    const long long g = t / LPB;
+    const int sub = (int)(t % LPB);
+    if (g >= (long long)a.rows * a.cols) return;   // whole groups drop out together (LPB | 256)
+    const int r = (int)(g / a.cols), c = (int)(g % a.cols);
+    const mv_t res = eval_block<BS, false, true>(a, r, c, sub, 0u);
+    if (sub == 0) {
+        a.est[g] = res;
+        // the blocks that read this one as an already-updated input assumed the old value
+        const mv_t old = a.old_grid[(size_t)(r >> a.old_shift) * a.old_cols + (c >> a.old_shift)];
+        if (res != old) mark_dependants(a, a.flag_next, r, c);
+    }
+}
+
+// Relaxation over the marked blocks, the whole chip at once, before the solver.  The grid is cut into tiles of
+// T x T blocks, one workgroup each.  A workgroup keeps the estimates of its tile (+ the ring of neighbours it reads:
+// one column left and right, one row above) in LDS, evaluates the marked blocks of the tile, and when a block
+// changes, queues its dependants R, DR, D, DL: those inside the tile for the workgroup's next LOCAL round (same
+// launch, a barrier apart), those outside in the byte map flag_next for the next launch.  After `local_rounds`
+// rounds whatever is still queued goes to flag_next too.  Plain loads and stores.  An estimate outside the tile is
+// read once, at the start; if its owner changes it during this launch, that owner marks the reader in flag_next.
+// This is asynchronous fixed-point iteration: any number of rounds or launches, followed by k_reg_solve, ends at
+// the same (unique) field.  It takes the first, heavy generations of a sweep -- thousands of stale blocks at once --
+// away from the solver, whose coherent traffic and memory-side atomics queue up under that load.
+template <int BS> struct RegIter {
+    static constexpr int T = BS <= 4 ? 32 : (BS == 8 ? 16 : 8);       // tile edge in blocks
+};
+template <int BS>
+__global__ __launch_bounds__(256) void k_reg_iter(RegArgs a)
+{
+    constexpr int LPB = RegCfg<BS>::LPB;
+    constexpr int T = RegIter<BS>::T;
+    constexpr int TP = T + 2;                                 // pitch of the LDS tile: halo column left and right
+    __shared__ mv_t tile[(T + 1) * TP];                       // row 0 = halo row above
+    __shared__ uint32_t list[2][T * T];
+    __shared__ uint32_t n_list[2];
+    __shared__ uint32_t queued[(T * T + 31) / 32];
+    const int t = threadIdx.x;
+    const int tiles_x = (a.cols + T - 1) / T;
+    const int r0 = ((int)blockIdx.x / tiles_x) * T, c0 = ((int)blockIdx.x % tiles_x) * T;
+    if (t < 2) n_list[t] = 0;
+    for (int i = t; i < (T + 1) * TP; i += 256) {
+        const int rr = r0 - 1 + i / TP, cc = c0 - 1 + i % TP;
+        tile[i] = (rr >= 0 && rr < a.rows && cc >= 0 && cc < a.cols) ? a.est[(size_t)rr * a.cols + cc] : 0u;
+    }
+    __syncthreads();
+    for (int i = t; i < T * T; i += 256) {                    // consume the tile's marks
+        const int lr = i / T, lc = i % T, rr = r0 + lr, cc = c0 + lc;
+        if (rr < a.rows && cc < a.cols) {
+            uint8_t *f = a.flag_cur + (size_t)rr * a.cols + cc;
+            if (*f) { *f = 0; list[0][atomicAdd(&n_list[0], 1u)] = (uint32_t)(lr * T + lc); }
+        }
+    }
+    const int sub = t % LPB;
+    int cur = 0, heavy = 0;
+    // a block changed: its dependants go on the tile's next list (once) or, outside the tile, into the byte map
+    auto propagate = [&](int lr, int lc, int r, int c, bool last) {
+        const int dr[4] = {0, 1, 1, 1}, dc[4] = {1, 1, 0, -1};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int lr2 = lr + dr[d], lc2 = lc + dc[d], rr = r + dr[d], cc = c + dc[d];
+            if (rr >= a.rows || cc < 0 || cc >= a.cols) continue;
+            if (!last && lr2 < T && lc2 >= 0 && lc2 < T) {
+                const uint32_t bit = (uint32_t)(lr2 * T + lc2);
+                if (!(atomicOr(&queued[bit >> 5], 1u << (bit & 31u)) & (1u << (bit & 31u))))
+                    list[cur ^ 1][atomicAdd(&n_list[cur ^ 1], 1u)] = bit;
+            } else {
+                a.flag_next[(size_t)rr * a.cols + cc] = 1;
+            }
+        }
+    };
+    for (int round = 0;; ++round) {
+        __syncthreads();
+        const uint32_t cnt = n_list[cur];
+        if (cnt == 0) break;                                  // uniform
+        // rounds with many blocks keep one CU busy while the chip waits: only `local_rounds` of them; rounds with
+        // up to 16 blocks are a chain being walked, which is cheapest right here (estimates in LDS, no atomics)
+        const bool chain = cnt <= 16u;
+        if (!chain) ++heavy;
+        const bool last = heavy >= a.local_rounds || round + 1 >= 96;
+        __syncthreads();
+        if (t == 0) n_list[cur ^ 1] = 0;
+        for (int i = t; i < (T * T + 31) / 32; i += 256) queued[i] = 0;
+        __syncthreads();
+        if (chain) {
+            // 16 lanes per block, lane k = candidate k (see eval_block_lanes)
+            const int g = t >> 4, k16 = t & 15;
+            if ((uint32_t)g < cnt) {
+                const int lr = (int)(list[cur][g] / T), lc = (int)(list[cur][g] % T);
+                const int r = r0 + lr, c = c0 + lc;
+                const int k = k16 < 9 ? k16 : 0;
+                const int rr = r + kNbRow[k], cc = c + kNbCol[k];
+                const bool present = k16 < 9 && rr >= 0 && rr < a.rows && cc >= 0 && cc < a.cols;
+                const int rs = min(max(rr, 0), a.rows - 1), cs = min(max(cc, 0), a.cols - 1);
+                mv_t mv;
+                if ((BBME_NEW_MASK >> k) & 1u) mv = tile[(lr + kNbRow[k] + 1) * TP + lc + kNbCol[k] + 1];
+                else mv = a.old_grid[(size_t)(rs >> a.old_shift) * a.old_cols + (cs >> a.old_shift)];
+                const mv_t res = lanes_score<BS>(a, r, c, k16, present, mv);
+                if (k16 == 0 && res != tile[(lr + 1) * TP + lc + 1]) {
+                    tile[(lr + 1) * TP + lc + 1] = res;
+                    a.est[(size_t)r * a.cols + c] = res;
+                    propagate(lr, lc, r, c, last);
+                }
+            }
+        } else {
+            for (uint32_t idx = t / LPB; idx < cnt; idx += 256 / LPB) {
+                const int lr = (int)(list[cur][idx] / T), lc = (int)(list[cur][idx] % T);
+                const int r = r0 + lr, c = c0 + lc;
+                mv_t cand[9];
+                uint32_t present = 0;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const int rr = r + kNbRow[k], cc = c + kNbCol[k];
+                    if (rr >= 0 && rr < a.rows && cc >= 0 && cc < a.cols) present |= 1u << k;
+                    const int rs = min(max(rr, 0), a.rows - 1), cs = min(max(cc, 0), a.cols - 1);
+                    if ((BBME_NEW_MASK >> k) & 1u) cand[k] = tile[(lr + kNbRow[k] + 1) * TP + lc + kNbCol[k] + 1];
+                    else cand[k] = a.old_grid[(size_t)(rs >> a.old_shift) * a.old_cols + (cs >> a.old_shift)];
+                }
+                bool uniform = true;
+#pragma unroll
+                for (int k = 1; k < 9; ++k) uniform &= !((present >> k) & 1u) || cand[k] == cand[0];
+                mv_t res = cand[0];
+                if (!uniform) res = score_block<BS, false>(a, cand, present, c * BS, r * BS, sub);
+                if (sub == 0 && res != tile[(lr + 1) * TP + lc + 1]) {
+                    tile[(lr + 1) * TP + lc + 1] = res;
+                    a.est[(size_t)r * a.cols + c] = res;
+                    propagate(lr, lc, r, c, last);
+                }
+            }
+        }
+        if (last) break;                                      // uniform
+        cur ^= 1;
+    }
+}
+
 // One work-list pass of the safety net (see k_reg_solve's epilogue): `nthreads` threads of one
 // workgroup, lists in global memory that cannot overflow (a block is on a list at most once).
 template <int BS>
@@ -780,15 +931,21 @@ __device__ __forceinline__ void drain_lists(const RegArgs &a, int t, int nthread
     }
 }
 
-// Asynchronous solver.  Every wave owns a private LDS queue.  It takes its share of the work list
-// k_reg_tile left (blocks one of whose already-updated inputs lies in another tile and came out different
-// from its old value; 16 at a time, so that a cluster of stale blocks is spread over many waves), claims and
-// queues those blocks, and whatever its own changes make stale it queues locally too and evaluates
-// itself, round after round, without any grid-wide step: fixed-point iteration tolerates any
-// evaluation order.  A wave whose queue is empty and whose share is done simply exits.  If a local
-// queue is full the surplus goes to a global overflow list; the workgroup that finishes last
-// (ticket counter) drains that list on its own, so the launch always ends at the fixed point.  The
-// same workgroup then files the sweep's counters for the diagnostics and clears them for the next sweep.
+// Asynchronous solver.  Every wave owns a private LDS queue.  It scans its share of the dirty flags
+// (blocks one of whose already-updated inputs was changed by pass 1 or by the last relaxation step),
+// claims and queues the marked blocks, and whatever its own changes make stale it queues locally too
+// and evaluates itself, round after round, without any grid-wide step: fixed-point iteration
+// tolerates any evaluation order.  A wave whose queue is empty and which has scanned its share simply
+// exits.  If a local queue is full the surplus goes to a global overflow list; the workgroup that
+// finishes last (ticket counter) drains that list on its own, so the launch always ends at the fixed
+// point.
+//
+// The scan: the flag map is cut into SEGMENTS of 16 flags (one 16-byte load).  XCD j owns the j-th band
+// of the raster (workgroups go round-robin to the 8 XCDs, each with its own L2: the estimates and
+// ownership words of a band are then read, written and claimed through one L2); inside a band segment
+// s belongs to wave s mod W of that XCD, so that a cluster of stale blocks is spread over many waves
+// instead of queueing up behind one, and a wave looks at 64 of its segments -- 1024 flags -- per memory
+// trip: a sweep that left nothing stale costs two trips at 2 M blocks, not 127.
 template <int BS>
 __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
 {
@@ -804,10 +961,12 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint32_t *q = qmem[wave];
-    constexpr uint32_t SCAN = 16;
+    const uint32_t nblocks = (uint32_t)a.rows * a.cols;
+    const uint32_t xcd = blockIdx.x & 7u;                  // the launch has a multiple of 8 workgroups
     const uint32_t wpw = blockDim.x >> 6;                  // waves per workgroup (1, 2 or 4)
-    const uint32_t w = blockIdx.x * wpw + wave, W = gridDim.x * wpw;
-    const uint32_t n_marks = min(__hip_atomic_load(a.mark_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a.mark_cap);
+    const uint32_t wx = (blockIdx.x >> 3) * wpw + wave, Wx = (gridDim.x >> 3) * wpw;
+    const uint32_t nseg = (nblocks + 15u) / 16u, band = (nseg + 7u) / 8u;
+    const uint32_t seg_begin = min(xcd * band, nseg), seg_end = min(seg_begin + band, nseg);
     uint32_t *ovf_list = a.list0;
     uint32_t *ovf_count = &a.counters[1];
     uint32_t head = 0, tail = 0;                  // wave-uniform, free-running
@@ -836,16 +995,26 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
         }
     };
 
-    for (uint32_t base = w * SCAN;; base += W * SCAN) {
-        if (base < n_marks) {
-            const uint32_t i = base + lane;
-            bool mine = false;
-            uint32_t x = 0;
-            if ((uint32_t)lane < SCAN && i < n_marks) {
-                x = a.mark_list[i];                            // written by the previous launch
-                mine = own_claim(a, x) == 0;                   // listed twice: the second claim makes its owner look again
+    for (uint32_t k = 0;; ++k) {
+        if (seg_begin + k * 64u * Wx + wx < seg_end) {
+            const uint32_t sg = seg_begin + (k * 64u + (uint32_t)lane) * Wx + wx;
+            uint4 f = make_uint4(0, 0, 0, 0);
+            uint4 *fp = reinterpret_cast<uint4 *>(a.flag_cur + (size_t)sg * 16);      // the map is padded to whole segments
+            if (sg < seg_end) f = *fp;
+            const bool any = (f.x | f.y | f.z | f.w) != 0;
+            if (__ballot(any)) {
+                if (any) *fp = make_uint4(0, 0, 0, 0);
+                const uint32_t fw[4] = {f.x, f.y, f.z, f.w};
+                // every claim of the step in flight at once (one memory trip), then the queue
+                uint32_t was[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    was[j] = 1;
+                    if ((fw[j >> 2] >> (8 * (j & 3))) & 0xffu) was[j] = own_claim(a, sg * 16u + (uint32_t)j);
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) enqueue(was[j] == 0, sg * 16u + (uint32_t)j);
             }
-            enqueue(mine, x);
         } else if (head == tail) {
             break;
         }
@@ -942,13 +1111,6 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
     __syncthreads();
     if (s_ticket != gridDim.x - 1) return;
     drain_lists<BS>(a, threadIdx.x, (int)blockDim.x);
-    __syncthreads();
-    if (threadIdx.x < 16) {
-        const uint32_t v = __hip_atomic_load(&a.counters[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a.counters[32 + threadIdx.x] = v;
-        if (threadIdx.x != 5) __hip_atomic_store(&a.counters[threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (threadIdx.x == 16) __hip_atomic_store(a.mark_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // =======================================================================================
