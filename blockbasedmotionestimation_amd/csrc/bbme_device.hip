@@ -27,9 +27,15 @@ namespace {
 struct Level {
     int width = 0, height = 0, block = 0, search = 0, range = 0;
     uint8_t *img1 = nullptr, *img2 = nullptr;     // padded planes, pitch == width
-    mv_t *grid[2] = {nullptr, nullptr};           // MV grids (capacity (H/2)*(W/2))
-    int cur = 0;                                  // which grid holds the current field
+    // MV grids.  small[]: grids at the level's own block size B (the search writes small[0]; the two sweeps at B go
+    // small[0] -> small[1] -> small[0], which then stays untouched until the level's next search: the speculative search
+    // of the next finer level predicts from it).  big[]: grids at b < B (capacity (H/2)*(W/2)), ping-pong.
+    mv_t *small[2] = {nullptr, nullptr};
+    mv_t *big[2] = {nullptr, nullptr};
+    mv_t *cur_grid = nullptr;                     // the grid that holds the current field
     int cur_block = 0;                            // its block size (0 = nothing yet)
+    mv_t *pred = nullptr;                         // per block: the coarse MV a speculative search started from
+    mv_t *final_grid() const { return block == 2 ? small[0] : big[1]; }   // where two sweeps per block size leave the 2x2 cells
     uint32_t *spiral = nullptr;                   // rank -> packed (dx, dy)
     int ncand = 0;
     int pitch_dw = 0;
@@ -68,6 +74,10 @@ struct bbme_ctx {
     int xcd_remap = 1;                            // XCD-aware block order in k_search_fast; BBME_XCD_REMAP
     bool force_generic_search = false;            // BBME_GENERIC_SEARCH=1: use k_search_generic everywhere
     bool use_graph = true;
+    bool speculate = true;                        // overlap every level's search with the coarser level's late sweeps; BBME_SPECULATE
+    hipStream_t side_stream = nullptr;            // the speculative searches
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    size_t spec_lds = 0;                          // LDS per workgroup of a speculative search launch (occupancy cap)
     hipGraphExec_t graph_exec = nullptr;
     bool profiling = false;
     float t_total = 0, t_search = 0, t_reg = 0, t_expand = 0, t_search0 = 0;
@@ -121,7 +131,38 @@ void launch_search_t(const SearchArgs &a, int nblocks, size_t lds, hipStream_t s
     hipLaunchKernelGGL(k_search_generic<B>, dim3(nblocks), dim3(64), lds, s, a);
 }
 
-int launch_search_fast(bbme_ctx *c, int level)
+// Where the search of `level` takes its predictions from (copyMVs, :828-843), by mode:
+//   plain / fix-up : the coarser level's final 2x2-cell grid (it must have been regularised down to 2x2);
+//   speculative    : the coarser level's grid as its two sweeps at its own block size left it (Level::small[0]).
+template <class Args>
+int set_prediction_source(bbme_ctx *c, int level, int mode, Args &a)
+{
+    Level &L = c->lv[level];
+    a.mode = mode;
+    a.pred = L.pred;
+    a.coarse = nullptr;
+    if (level + 1 >= (int)c->lv.size()) return BBME_OK;
+    Level &C = c->lv[level + 1];
+    a.coarse_block = C.block;
+    if (mode == kSearchSpeculative) {
+        if (C.cur_block != C.block || C.cur_grid != C.small[0])
+            return bbme::fail(BBME_ERR_STATE, "level %d is not at the end of the sweeps at its own block size", level + 1);
+        a.coarse = C.small[0];
+        a.coarse_cell_shift = 0;
+        while ((1 << a.coarse_cell_shift) < C.block) ++a.coarse_cell_shift;
+    } else {
+        if (C.cur_block != 2)
+            return bbme::fail(BBME_ERR_STATE, "level %d has not been regularised down to 2x2 blocks", level + 1);
+        a.coarse = C.cur_grid;
+        a.coarse_cell_shift = 1;
+    }
+    a.coarse_cols = C.width >> a.coarse_cell_shift;
+    return BBME_OK;
+}
+
+// `lds_floor`: dynamic LDS to ask for at least -- the speculative launch pads its workgroups so that only
+// ctx::spec_wgs_per_cu of them fit a CU and the regulariser's kernels beside it still find wave slots, registers and LDS.
+int launch_search_fast(bbme_ctx *c, int level, int mode, hipStream_t stream, size_t lds_floor)
 {
     Level &L = c->lv[level];
     FastSearchArgs a{};
@@ -130,63 +171,56 @@ int launch_search_fast(bbme_ctx *c, int level)
     a.range = L.range; a.spiral = L.spiral;
     a.rank_of = L.rank_of; a.rank_pitch = L.rank_pitch;
     a.tasks = L.tasks; a.rounds = L.rounds; a.nrounds = L.nrounds;
-    if (level + 1 < (int)c->lv.size()) {
-        Level &C = c->lv[level + 1];
-        if (C.cur_block != 2)
-            return bbme::fail(BBME_ERR_STATE, "level %d has not been regularised down to 2x2 blocks", level + 1);
-        a.coarse = C.grid[C.cur];
-        a.coarse_cols = C.width / 2;
-        a.coarse_block = C.block;
-    }
-    L.cur = 0; L.cur_block = L.block;
-    a.out = L.grid[0];
+    if (int rc = set_prediction_source(c, level, mode, a)) return rc;
+    a.out = L.small[0];
     a.cols = L.width / L.block;
     a.pitch_dw = L.fast_pitch_dw;
     const int nblocks = (L.width / L.block) * (L.height / L.block);
     a.nblocks = nblocks;
     a.xcd_remap = c->xcd_remap;
     const int grid = c->xcd_remap ? ((nblocks + 7) / 8) * 8 : nblocks;
+    const size_t lds = std::max(L.fast_lds_bytes, lds_floor);
     if (L.block == 16)
-        hipLaunchKernelGGL(k_search_fast<16>, dim3(grid), dim3(64), L.fast_lds_bytes, c->stream, a);
+        hipLaunchKernelGGL(k_search_fast<16>, dim3(grid), dim3(64), lds, stream, a);
     else if (L.block == 32)
-        hipLaunchKernelGGL(k_search_fast<32>, dim3(grid), dim3(64), L.fast_lds_bytes, c->stream, a);
+        hipLaunchKernelGGL(k_search_fast<32>, dim3(grid), dim3(64), lds, stream, a);
     else
-        hipLaunchKernelGGL(k_search_fast<8>, dim3(grid), dim3(64), L.fast_lds_bytes, c->stream, a);
+        hipLaunchKernelGGL(k_search_fast<8>, dim3(grid), dim3(64), lds, stream, a);
     HIP_TRY(hipGetLastError());
     return BBME_OK;
 }
 
-int launch_search(bbme_ctx *c, int level)
+int launch_search(bbme_ctx *c, int level, int mode = kSearchPlain, hipStream_t stream = nullptr, size_t lds_floor = 0)
 {
     Level &L = c->lv[level];
-    if (L.fast && !c->force_generic_search) return launch_search_fast(c, level);
-    SearchArgs a{};
-    a.image1 = L.img1; a.image2 = L.img2;
-    a.width = L.width; a.height = L.height;
-    a.range = L.range; a.ncand = L.ncand; a.spiral = L.spiral;
-    if (level + 1 < (int)c->lv.size()) {
-        Level &C = c->lv[level + 1];
-        if (C.cur_block != 2)
-            return bbme::fail(BBME_ERR_STATE, "level %d has not been regularised down to 2x2 blocks", level + 1);
-        a.coarse = C.grid[C.cur];
-        a.coarse_cols = C.width / 2;
-        a.coarse_block = C.block;
+    if (!stream) stream = c->stream;
+    int rc;
+    if (L.fast && !c->force_generic_search) {
+        rc = launch_search_fast(c, level, mode, stream, lds_floor);
+    } else {
+        SearchArgs a{};
+        a.image1 = L.img1; a.image2 = L.img2;
+        a.width = L.width; a.height = L.height;
+        a.range = L.range; a.ncand = L.ncand; a.spiral = L.spiral;
+        if ((rc = set_prediction_source(c, level, mode, a))) return rc;
+        a.out = L.small[0];
+        a.cols = L.width / L.block;
+        a.pitch_dw = L.pitch_dw;
+        const int nblocks = (L.width / L.block) * (L.height / L.block);
+        const size_t lds = std::max(L.lds_bytes, lds_floor);
+        switch (L.block) {
+        case 4:  launch_search_t<4>(a, nblocks, lds, stream); break;
+        case 8:  launch_search_t<8>(a, nblocks, lds, stream); break;
+        case 16: launch_search_t<16>(a, nblocks, lds, stream); break;
+        case 32: launch_search_t<32>(a, nblocks, lds, stream); break;
+        case 64: launch_search_t<64>(a, nblocks, lds, stream); break;
+        default: return bbme::fail(BBME_ERR_UNSUPPORTED, "block size %d", L.block);
+        }
+        HIP_TRY(hipGetLastError());
+        rc = BBME_OK;
     }
-    L.cur = 0; L.cur_block = L.block;
-    a.out = L.grid[0];
-    a.cols = L.width / L.block;
-    a.pitch_dw = L.pitch_dw;
-    const int nblocks = (L.width / L.block) * (L.height / L.block);
-    switch (L.block) {
-    case 4:  launch_search_t<4>(a, nblocks, L.lds_bytes, c->stream); break;
-    case 8:  launch_search_t<8>(a, nblocks, L.lds_bytes, c->stream); break;
-    case 16: launch_search_t<16>(a, nblocks, L.lds_bytes, c->stream); break;
-    case 32: launch_search_t<32>(a, nblocks, L.lds_bytes, c->stream); break;
-    case 64: launch_search_t<64>(a, nblocks, L.lds_bytes, c->stream); break;
-    default: return bbme::fail(BBME_ERR_UNSUPPORTED, "block size %d", L.block);
-    }
-    HIP_TRY(hipGetLastError());
-    return BBME_OK;
+    if (rc == BBME_OK && mode != kSearchSpeculative) { L.cur_grid = L.small[0]; L.cur_block = L.block; }
+    return rc;
 }
 
 template <int BS>
@@ -226,9 +260,11 @@ int launch_sweep(bbme_ctx *c, int level, int b, int mult)
     a.image1 = L.img1; a.image2 = L.img2;
     a.width = L.width; a.height = L.height;
     a.rows = L.height / b; a.cols = L.width / b;
-    a.old_grid = L.grid[L.cur];
+    a.old_grid = L.cur_grid;
     a.old_cols = a.cols >> a.old_shift;
-    a.est = L.grid[L.cur ^ 1];
+    // sweeps at the level's own block size ping-pong in small[], the others in big[] (see Level)
+    mv_t *const *pool = (b == L.block) ? L.small : L.big;
+    a.est = (L.cur_grid == pool[0]) ? pool[1] : pool[0];
     // lambda = (float)(B/2), doubled at every halving (motion_framework.cpp:73,95,151); times
     // (float)lambda_multiplier as at :607
     float lambda = (float)(L.block / 2);
@@ -271,7 +307,7 @@ int launch_sweep(bbme_ctx *c, int level, int b, int mult)
     default: return bbme::fail(BBME_ERR_UNSUPPORTED, "block size %d", b);
     }
     HIP_TRY(hipGetLastError());
-    L.cur ^= 1;
+    L.cur_grid = a.est;
     L.cur_block = b;
     return BBME_OK;
 }
@@ -283,19 +319,36 @@ int launch_expand(bbme_ctx *c)
     const int cc = L.width / 2, cr = L.height / 2;
     const long long threads = (long long)cc * cr * 2;
     hipLaunchKernelGGL(k_expand, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream,
-                       L.grid[L.cur], cc, cr, c->flow, L.width);
+                       L.cur_grid, cc, cr, c->flow, L.width);
     HIP_TRY(hipGetLastError());
     return BBME_OK;
 }
 
-// The level loop of MF::calcMotionBlockMatching (:115-206)
-int enqueue_pyramid(bbme_ctx *c)
+// The level loop of MF::calcMotionBlockMatching (:115-206).  With `speculate`, the search of level l-1 is started on a
+// second stream as soon as level l has finished the two sweeps at its own block size, and runs beside the level's
+// remaining sweeps (which are latency-bound and leave most of the chip idle); when the level is final, a fix-up launch
+// searches again the blocks whose prediction those sweeps changed (search_prediction, bbme_kernels.hpp).
+int enqueue_pyramid(bbme_ctx *c, bool speculate)
 {
-    for (int l = (int)c->lv.size() - 1; l >= 0; --l) {
-        if (int rc = launch_search(c, l)) return rc;
-        for (int b = c->lv[l].block; b > 1; b >>= 1)              // while (block_size > 1) :141
+    const int nl = (int)c->lv.size();
+    bool speculated = false;
+    for (int l = nl - 1; l >= 0; --l) {
+        if (speculated) {
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+            if (int rc = launch_search(c, l, kSearchFixup)) return rc;
+        } else if (int rc = launch_search(c, l)) return rc;
+        speculated = false;
+        for (int b = c->lv[l].block; b > 1; b >>= 1) {            // while (block_size > 1) :141
             for (int mult = 1; mult <= 2; ++mult)                  // lambda_multiplier = l + 1 :145
                 if (int rc = launch_sweep(c, l, b, mult)) return rc;
+            if (speculate && l > 0 && b == c->lv[l].block && b > 2) {
+                HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+                HIP_TRY(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+                if (int rc = launch_search(c, l - 1, kSearchSpeculative, c->side_stream, c->spec_lds)) return rc;
+                HIP_TRY(hipEventRecord(c->ev_join, c->side_stream));
+                speculated = true;
+            }
+        }
     }
     return launch_expand(c);
 }
@@ -378,6 +431,14 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
     if (const char *e = getenv("BBME_SOLVE_WAVES")) { const int v = atoi(e); c->solve_waves = v <= 1 ? 1 : (v == 2 ? 2 : 4); }
     if (const char *e = getenv("BBME_TEST_ROUND_CAP")) c->round_cap = std::max(0, atoi(e));
     if (const char *e = getenv("BBME_NO_GRAPH")) c->use_graph = atoi(e) == 0;
+    if (const char *e = getenv("BBME_SPECULATE")) c->speculate = atoi(e) != 0;
+    {
+        // a speculative search may keep at most this many of its (one-wave) workgroups on a CU: the rest of the CU's wave
+        // slots, registers and LDS (40 KB) stay free for the regulariser kernels it runs beside
+        int per_cu = 8;
+        if (const char *e = getenv("BBME_SPEC_WGS_PER_CU")) per_cu = std::max(1, std::min(32, atoi(e)));
+        c->spec_lds = ((size_t)(160 - 40) * 1024 / per_cu) / 256 * 256;
+    }
     if (const char *e = getenv("BBME_GENERIC_SEARCH")) c->force_generic_search = atoi(e) != 0;
     if (const char *e = getenv("BBME_XCD_REMAP")) c->xcd_remap = atoi(e) != 0;
     c->lv.resize(nl);
@@ -385,6 +446,10 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
     hipError_t err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (err != hipSuccess) return cleanup_fail(bbme::fail(BBME_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(err)));
     c->own_stream = true;
+    if ((err = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (err = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess ||
+        (err = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess)
+        return cleanup_fail(bbme::fail(BBME_ERR_HIP, "creating the side stream: %s", hipGetErrorString(err)));
     size_t max_blocks = 0;
     for (int l = 0; l < nl; ++l) {
         Level &L = c->lv[l];
@@ -396,13 +461,17 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
         L.lds_bytes = ((size_t)(L.block + 2 * L.range) * L.pitch_dw + (size_t)L.block * L.block / 4) * 4;
         const size_t plane = (size_t)L.width * L.height + 64;          // slack: row_sad may touch 3 bytes past the end
         const size_t cells = (size_t)(L.width / 2) * (L.height / 2);
+        const size_t own_blocks = (size_t)(L.width / L.block) * (L.height / L.block);
         max_blocks = std::max(max_blocks, cells);
         std::vector<uint32_t> packed(sp.dx.size());
         for (size_t i = 0; i < sp.dx.size(); ++i)
             packed[i] = ((uint32_t)(uint16_t)sp.dx[i]) | ((uint32_t)(uint16_t)sp.dy[i] << 16);
         if ((err = hipMalloc(&L.img1, plane)) != hipSuccess || (err = hipMalloc(&L.img2, plane)) != hipSuccess ||
-            (err = hipMalloc(&L.grid[0], cells * sizeof(mv_t))) != hipSuccess ||
-            (err = hipMalloc(&L.grid[1], cells * sizeof(mv_t))) != hipSuccess ||
+            (err = hipMalloc(&L.small[0], own_blocks * sizeof(mv_t))) != hipSuccess ||
+            (err = hipMalloc(&L.small[1], own_blocks * sizeof(mv_t))) != hipSuccess ||
+            (err = hipMalloc(&L.pred, own_blocks * sizeof(mv_t))) != hipSuccess ||
+            (err = hipMalloc(&L.big[0], cells * sizeof(mv_t))) != hipSuccess ||
+            (err = hipMalloc(&L.big[1], cells * sizeof(mv_t))) != hipSuccess ||
             (err = hipMalloc(&L.spiral, packed.size() * 4)) != hipSuccess ||
             (err = hipMemset(L.img1, 0, plane)) != hipSuccess || (err = hipMemset(L.img2, 0, plane)) != hipSuccess ||
             (err = hipMemcpy(L.spiral, packed.data(), packed.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
@@ -457,7 +526,8 @@ int bbme_destroy(bbme_ctx *c)
     drop_graph(c);
     for (Level &L : c->lv) {
         (void)hipFree(L.img1); (void)hipFree(L.img2);
-        (void)hipFree(L.grid[0]); (void)hipFree(L.grid[1]); (void)hipFree(L.spiral);
+        (void)hipFree(L.small[0]); (void)hipFree(L.small[1]); (void)hipFree(L.pred);
+        (void)hipFree(L.big[0]); (void)hipFree(L.big[1]); (void)hipFree(L.spiral);
         (void)hipFree(L.rank_of); (void)hipFree(L.tasks); (void)hipFree(L.rounds);
     }
     (void)hipFree(c->flow);
@@ -465,6 +535,9 @@ int bbme_destroy(bbme_ctx *c)
     (void)hipFree(c->own);
     (void)hipFree(c->flags[0]); (void)hipFree(c->flags[1]);
     (void)hipFree(c->counters);
+    if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return BBME_OK;
@@ -596,12 +669,12 @@ int bbme_estimate(bbme_ctx *c)
     if (!c->frames_set) return bbme::fail(BBME_ERR_STATE, "bbme_estimate: no frames set");
     HIP_TRY(hipSetDevice(c->device));
     if (c->profiling) return profiled_pyramid(c);
-    if (!c->use_graph) return enqueue_pyramid(c);
+    if (!c->use_graph) return enqueue_pyramid(c, c->speculate);
     if (!c->graph_exec) {
         // the launch sequence is fixed (no host decisions inside), so capture it once
         hipGraph_t graph = nullptr;
         HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        int rc = enqueue_pyramid(c);
+        int rc = enqueue_pyramid(c, c->speculate);
         hipError_t e = hipStreamEndCapture(c->stream, &graph);
         if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
         if (e != hipSuccess) return bbme::fail(BBME_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
@@ -609,9 +682,8 @@ int bbme_estimate(bbme_ctx *c)
         (void)hipGraphDestroy(graph);
         if (e != hipSuccess) { c->graph_exec = nullptr; return bbme::fail(BBME_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
     } else {
-        // keep the host-side grid bookkeeping in step with what the graph replays: two sweeps
-        // per block size leave every level's field in grid[0], at 2x2 cells
-        for (Level &L : c->lv) { L.cur = 0; L.cur_block = 2; }
+        // keep the host-side grid bookkeeping in step with what the graph replays
+        for (Level &L : c->lv) { L.cur_grid = L.final_grid(); L.cur_block = 2; }
     }
     HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
     return BBME_OK;
@@ -650,7 +722,7 @@ int bbme_get_cells_host(bbme_ctx *c, int16_t *cells)
     if (L.cur_block != 2) return bbme::fail(BBME_ERR_STATE, "level 0 is not at 2x2 cells");
     HIP_TRY(hipSetDevice(c->device));
     const size_t n = (size_t)(L.width / 2) * (L.height / 2);
-    HIP_TRY(hipMemcpyAsync(cells, L.grid[L.cur], n * sizeof(mv_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(cells, L.cur_grid, n * sizeof(mv_t), hipMemcpyDeviceToHost, c->stream));
     return check_converged(c);
 }
 
@@ -658,8 +730,8 @@ int bbme_cells_device(bbme_ctx *c, const int16_t **d_cells)
 {
     if (int rc = check_ctx(c)) return rc;
     if (!d_cells) return bbme::fail(BBME_ERR_INVALID, "null output");
-    // two sweeps per block size leave the final field of every level in grid[0] (see bbme_estimate)
-    *d_cells = reinterpret_cast<const int16_t *>(c->lv[0].grid[0]);
+    // two sweeps per block size always leave the final field of a level in the same buffer (Level::final_grid)
+    *d_cells = reinterpret_cast<const int16_t *>(c->lv[0].final_grid());
     return BBME_OK;
 }
 
@@ -700,7 +772,7 @@ int bbme_calculate_mse_device(bbme_ctx *c, const float *d_gtruth, int gt_width, 
     double *d_sum = nullptr;
     HIP_TRY(hipMalloc(&d_sum, kMaxGroups * (sizeof(double) + sizeof(unsigned long long))));
     unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>(d_sum + kMaxGroups);
-    hipLaunchKernelGGL(k_epe, dim3(groups), dim3(256), 0, c->stream, L.grid[L.cur], L.width / 2,
+    hipLaunchKernelGGL(k_epe, dim3(groups), dim3(256), 0, c->stream, L.cur_grid, L.width / 2,
                        c->geom.pad_x, c->geom.pad_y, scale, d_gtruth, gt_width, gt_height, d_sum, d_cnt);
     std::vector<double> h_sum(kMaxGroups);
     std::vector<unsigned long long> h_cnt(kMaxGroups);
@@ -745,7 +817,7 @@ int bbme_stage_get_mvs(bbme_ctx *c, int level, int block, int16_t *mvs)
     HIP_TRY(hipSetDevice(c->device));
     const int rows = L.height / L.cur_block, cols = L.width / L.cur_block;
     std::vector<mv_t> host((size_t)rows * cols);
-    HIP_TRY(hipMemcpyAsync(host.data(), L.grid[L.cur], host.size() * sizeof(mv_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(host.data(), L.cur_grid, host.size() * sizeof(mv_t), hipMemcpyDeviceToHost, c->stream));
     if (int rc = check_converged(c)) return rc;
     // divide_blocks (:845-862) repeated: every finer block inherits its parent's MV
     const int f = L.cur_block / block, orows = rows * f, ocols = cols * f;
@@ -769,8 +841,9 @@ int bbme_stage_set_mvs(bbme_ctx *c, int level, int block, const int16_t *mvs)
     const size_t n = (size_t)(L.height / block) * (L.width / block);
     std::vector<mv_t> host(n);
     for (size_t i = 0; i < n; ++i) host[i] = ((uint32_t)(uint16_t)mvs[2 * i]) | ((uint32_t)(uint16_t)mvs[2 * i + 1] << 16);
-    L.cur = 0; L.cur_block = block;
-    HIP_TRY(hipMemcpyAsync(L.grid[0], host.data(), n * sizeof(mv_t), hipMemcpyHostToDevice, c->stream));
+    L.cur_grid = block == L.block ? L.small[0] : L.big[0];
+    L.cur_block = block;
+    HIP_TRY(hipMemcpyAsync(L.cur_grid, host.data(), n * sizeof(mv_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return BBME_OK;
 }

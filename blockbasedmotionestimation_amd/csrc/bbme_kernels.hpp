@@ -34,13 +34,38 @@ struct SearchArgs {
     int range;                  // R
     int ncand;                  // (2R+1)^2
     const uint32_t *spiral;     // rank -> (dx & 0xffff) | (dy << 16)
-    const mv_t *coarse;         // final 2x2-cell grid of level l+1, or nullptr (coarsest level)
-    int coarse_cols;            // its row length = W_{l+1} / 2
+    const mv_t *coarse;         // MV grid of level l+1 at cells of 1 << coarse_cell_shift pixels, or nullptr (coarsest level)
+    int coarse_cols;            // its row length = W_{l+1} >> coarse_cell_shift
     int coarse_block;           // B_{l+1}
+    int coarse_cell_shift;      // 1: the final 2x2-cell grid; log2(B_{l+1}): the grid after the sweeps at B_{l+1} (speculation)
+    int mode;                   // kSearchPlain / kSearchSpeculative / kSearchFixup (see search_prediction)
+    mv_t *pred;                 // per block of this level: the coarse MV a speculative search started from
     mv_t *out;                  // (H/B) x (W/B)
     int cols;                   // W / B
     int pitch_dw;               // LDS window pitch in dwords
 };
+
+// copyMVs (:828-843) as the search kernels see it: the MV of the coarse block covering pixel (i, j) of this level.
+// A block's search result depends on its prediction alone, which is what makes the search of level l speculable:
+//   kSearchSpeculative  runs beside the late sweeps of level l+1 (second stream), predicting from the grid as the two
+//                       sweeps at B_{l+1} left it, and records the coarse MV it used;
+//   kSearchFixup        after level l+1 is final: a block whose recorded MV equals the final one (the top-left 2x2 cell
+//                       of the coarse block, which is all copyMVs reads) keeps its result, the others are searched again.
+// Either way every block ends with the result of a search from the final prediction: bit-exact by construction.
+enum { kSearchPlain = 0, kSearchSpeculative = 1, kSearchFixup = 2 };
+template <class Args>
+__device__ __forceinline__ bool search_prediction(const Args &a, int i, int j, uint32_t bid, mv_t &m)
+{
+    m = 0;
+    if (a.coarse) {
+        const int ci = (i / (2 * a.coarse_block)) * a.coarse_block;
+        const int cj = (j / (2 * a.coarse_block)) * a.coarse_block;
+        m = a.coarse[(size_t)(ci >> a.coarse_cell_shift) * a.coarse_cols + (cj >> a.coarse_cell_shift)];
+    }
+    if (a.mode == kSearchFixup && a.pred[bid] == m) return false;       // searched from this prediction already
+    if (a.mode == kSearchSpeculative && threadIdx.x == 0) a.pred[bid] = m;
+    return true;
+}
 
 template <int B>
 __global__ __launch_bounds__(64) void k_search_generic(SearchArgs a)
@@ -52,13 +77,9 @@ __global__ __launch_bounds__(64) void k_search_generic(SearchArgs a)
     const int i = br * B, j = bc * B;                     // block origin (row, col)
 
     // copyMVs: the coarse block covering pixel (i, j) of this level, MV doubled (:836-840)
-    int u = 0, v = 0;
-    if (a.coarse) {
-        const int ci = (i / (2 * a.coarse_block)) * a.coarse_block;
-        const int cj = (j / (2 * a.coarse_block)) * a.coarse_block;
-        const mv_t m = a.coarse[(size_t)(ci >> 1) * a.coarse_cols + (cj >> 1)];
-        u = 2 * mv_x(m); v = 2 * mv_y(m);
-    }
+    mv_t m;
+    if (!search_prediction(a, i, j, blockIdx.x, m)) return;
+    const int u = 2 * mv_x(m), v = 2 * mv_y(m);
     const int px = j + u, py = i + v;                      // :233-234
     mv_t *dst = a.out + (size_t)br * a.cols + bc;
     if (px < 0 || py < 0 || px + B > a.width || py + B > a.height) {   // :304-310 -> zero MV
@@ -152,8 +173,10 @@ struct FastSearchArgs {
     const uint32_t *tasks;      // nrounds * 64 entries: g | dy0 << 8, 0xffffffff = idle lane
     const uint32_t *rounds;     // nrounds entries: strip height S
     int nrounds;
-    const mv_t *coarse;
-    int coarse_cols, coarse_block;
+    const mv_t *coarse;         // prediction source, as in SearchArgs
+    int coarse_cols, coarse_block, coarse_cell_shift;
+    int mode;
+    mv_t *pred;
     mv_t *out;
     int cols;
     int pitch_dw;               // LDS window pitch in dwords (odd)
@@ -276,28 +299,15 @@ __device__ __forceinline__ uint32_t search_strip(const uint32_t *win, int P, con
     return best;
 }
 
+// The search of macroblock `bid` from the coarse MV `m` (one wave; smem = the workgroup's dynamic LDS).
 template <int B>
-__global__ __launch_bounds__(64) void k_search_fast(FastSearchArgs a)
+__device__ __forceinline__ void search_block_fast(const FastSearchArgs &a, uint32_t bid, mv_t m, uint32_t *smem)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     constexpr int BW = B / 4;
     const int lane = threadIdx.x;
-    // Workgroups are dealt round-robin over the 8 XCDs, each with a private L2.  Give every XCD a
-    // contiguous eighth of the raster so that neighbouring macroblocks -- whose windows overlap by
-    // 80 % -- meet in the same L2.  Pure speed: any placement gives the same result.
-    const uint32_t chunk = (uint32_t)(a.nblocks + 7) / 8;
-    const uint32_t bid = a.xcd_remap ? (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3) : blockIdx.x;
-    if (bid >= (uint32_t)a.nblocks) return;
     const int bc = (int)(bid % (uint32_t)a.cols), br = (int)(bid / (uint32_t)a.cols);
     const int i = br * B, j = bc * B;
-
-    int u = 0, v = 0;                                       // copyMVs (:828-843)
-    if (a.coarse) {
-        const int ci = (i / (2 * a.coarse_block)) * a.coarse_block;
-        const int cj = (j / (2 * a.coarse_block)) * a.coarse_block;
-        const mv_t m = a.coarse[(size_t)(ci >> 1) * a.coarse_cols + (cj >> 1)];
-        u = 2 * mv_x(m); v = 2 * mv_y(m);
-    }
+    const int u = 2 * mv_x(m), v = 2 * mv_y(m);             // copyMVs doubles the coarse MV (:836)
     const int px = j + u, py = i + v;                       // :233-234
     mv_t *dst = a.out + (size_t)br * a.cols + bc;
     if (px < 0 || py < 0 || px + B > a.width || py + B > a.height) {    // :304-310
@@ -371,6 +381,21 @@ __global__ __launch_bounds__(64) void k_search_fast(FastSearchArgs a)
         const uint32_t sp = a.spiral[best & (B > 16 ? 0x3fffu : 0xffffu)];
         *dst = mv_pack(u + (int)(int16_t)(sp & 0xffffu), v + (int)(int16_t)(sp >> 16));   // :238-239
     }
+}
+
+template <int B>
+__global__ __launch_bounds__(64) void k_search_fast(FastSearchArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    // Workgroups are dealt round-robin over the 8 XCDs, each with a private L2.  Give every XCD a
+    // contiguous eighth of the raster so that neighbouring macroblocks -- whose windows overlap by
+    // 80 % -- meet in the same L2.  Pure speed: any placement gives the same result.
+    const uint32_t chunk = (uint32_t)(a.nblocks + 7) / 8;
+    const uint32_t bid = a.xcd_remap ? (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3) : blockIdx.x;
+    if (bid >= (uint32_t)a.nblocks) return;
+    mv_t m;                                                 // copyMVs (:828-843)
+    if (!search_prediction(a, (int)(bid / (uint32_t)a.cols) * B, (int)(bid % (uint32_t)a.cols) * B, bid, m)) return;
+    search_block_fast<B>(a, bid, m, smem);
 }
 
 // =======================================================================================
@@ -742,6 +767,7 @@ template <int BS>
 __global__ __launch_bounds__(256) void k_reg_pass1(RegArgs a)
 {
     constexpr int LPB = RegCfg<BS>::LPB;
+    __builtin_amdgcn_s_setprio(2);                 // latency-bound: ahead of a speculative search sharing the SIMD
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     // the solver's counters (nothing else touches them before this sweep's solver launch)
     if (t < 16 && t != 5) a.counters[t] = 0;
@@ -781,6 +807,7 @@ __global__ __launch_bounds__(256) void k_reg_iter(RegArgs a)
     __shared__ uint32_t list[2][T * T];
     __shared__ uint32_t n_list[2];
     __shared__ uint32_t queued[(T * T + 31) / 32];
+    __builtin_amdgcn_s_setprio(2);
     const int t = threadIdx.x;
     const int tiles_x = (a.cols + T - 1) / T;
     const int r0 = ((int)blockIdx.x / tiles_x) * T, c0 = ((int)blockIdx.x % tiles_x) * T;
@@ -958,6 +985,7 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
     constexpr uint32_t QCAP = 1024;
     __shared__ uint32_t qmem[4][QCAP];
     __shared__ uint32_t s_ticket;
+    __builtin_amdgcn_s_setprio(2);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint32_t *q = qmem[wave];
