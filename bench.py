@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_SAD_PEAK_T = 157.3               # T abs-diff/s: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz x 4 (v_sad_u8), SURVEY.md 8d
 
 WORKLOADS = {
     # name: (width, height, search_size, block_size, levels, description)
@@ -46,20 +47,24 @@ def level_blocks(pw, ph, block, levels):
 
 def pmc_traffic(levels):
     """Mean HBM-side bytes per search launch from the committed rocprofv3 --pmc passes
-    (profiles/r01_pmc_search.json, made by scripts/pmc_report.py: FETCH_SIZE scaled by the factor
+    (profiles/rNN_pmc_search.json, made by scripts/pmc_report.py: FETCH_SIZE scaled by the factor
     measured on a calibration read of known size in the same run, plus WRITE_SIZE).  Only quoted
-    when that file was measured on exactly this kernel source; otherwise None."""
+    when a file was measured on exactly this kernel source; otherwise None."""
+    import glob
     import hashlib
-    path = os.path.join(ROOT, "profiles", "r01_pmc_search.json")
     src = os.path.join(ROOT, "blockbasedmotionestimation_amd", "csrc", "bbme_kernels.hpp")
-    try:
-        d = json.load(open(path))
-        if d.get("kernel_source_sha256") != hashlib.sha256(open(src, "rb").read()).hexdigest():
-            return None
-        vals = [v["hbm_bytes"] for k, v in d["kernels"].items() if k.startswith("k_search")]
-        return sum(vals) / len(vals) if len(vals) == levels else None
-    except (OSError, ValueError, KeyError):
-        return None
+    digest = hashlib.sha256(open(src, "rb").read()).hexdigest()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_search.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            if d.get("kernel_source_sha256") != digest:
+                continue
+            vals = [v["hbm_bytes"] for k, v in d["kernels"].items() if k.startswith("k_search")]
+            if len(vals) == levels:
+                return sum(vals) / len(vals)
+        except (OSError, ValueError, KeyError):
+            pass
+    return None
 
 
 def epe_on_ground_truth(bbme, device):
@@ -220,6 +225,7 @@ def main():
             ctxs.append(bbme.MF(torch.from_numpy(g1).cuda(), torch.from_numpy(g2).cuda(), [search] * levels,
                                 [block] * levels, levels, device=local_rank, frames_on_device=True))
         for c in ctxs:
+            c.set_speculation(False)              # with pairs in flight the chip is busy anyway
             c.estimate_async()
         for c in ctxs:
             c.synchronize()
@@ -238,6 +244,7 @@ def main():
                     "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}
         for c in ctxs[1:]:
             c.close()
+        mf.set_speculation(True)
 
     # the boundary with host buffers (never `value`): frames in (pinned) host memory -> upload (2 x 8.3 MB at 4K), padding +
     # pyramid on the GPU, estimate, download of the dense field (66.8 MB) or of the compact 2x2-cell grid (4.2 MB)
@@ -246,25 +253,54 @@ def main():
         p1, p2 = torch.from_numpy(f1).pin_memory(), torch.from_numpy(f2).pin_memory()
         reps = 5
 
-        def through_host(get):
+        def through_host(get, reps=reps):
             mf.synchronize()
             t0 = time.perf_counter()
-            for _ in range(reps):
+            for i in range(reps):
                 t1.copy_(p1, non_blocking=True)
                 t2.copy_(p2, non_blocking=True)
-                torch.cuda.synchronize()
-                mf.set_frames_device(t1, t2)
+                mf.set_frames_device(t1, t2)      # orders the context's stream behind the two uploads
                 mf.estimate_async()
-                get()
+                get(i)
             return (time.perf_counter() - t0) / reps * 1e3
-        pin_flow = torch.empty((ph, pw, 2), dtype=torch.float32).pin_memory().numpy()
+        pin_flow = [torch.empty((ph, pw, 2), dtype=torch.float32).pin_memory().numpy() for _ in range(2)]
         pin_cells = torch.empty((ph // 2, pw // 2, 2), dtype=torch.int16).pin_memory().numpy()
-        dense_ms = through_host(lambda: mf.get_flow(pin_flow))
-        cells_ms = through_host(lambda: mf.get_cells(pin_cells))
+        dense_ms = through_host(lambda i: mf.get_flow(pin_flow[0]))
+        cells_ms = through_host(lambda i: mf.get_cells(pin_cells))
+        # end to end as the reference's driver would be with its writer called (main_class.cpp:24-75 + rw_flow.cpp:139-200):
+        # ... download, strip the padding, Flow::WriteFlowFile -- synchronously, and with the asynchronous writer
+        # (bbme_flo_writer_*: the file of pair i is written from pinned memory while pair i + 1 is estimated)
+        out_dir = tempfile.mkdtemp(prefix="bbme_flo_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        flo = bbme.Flow()
+
+        def write_sync(i):
+            fl = mf.get_flow(pin_flow[0])
+            flo.WriteFlowFile(fl[mf.padding_y:mf.padding_y + h, mf.padding_x:mf.padding_x + w], os.path.join(out_dir, "s%d.flo" % i))
+        sync_ms = through_host(write_sync)
+        writer = bbme.FlowWriter()
+
+        def write_async(i):
+            if i >= 2:
+                pass                                  # buffer i & 1 was submitted two pairs ago; the writer is FIFO
+            if i >= 1:
+                writer.wait()                         # pair i - 1's file is complete (it was written during this estimate)
+            fl = mf.get_flow(pin_flow[i & 1])
+            writer.submit(fl, os.path.join(out_dir, "a%d.flo" % i), mf.padding_x, mf.padding_y, w, h)
+        async_ms = through_host(write_async, reps=8)
+        writer.wait()
+        same_file = open(os.path.join(out_dir, "s0.flo"), "rb").read() == open(os.path.join(out_dir, "a0.flo"), "rb").read()
+        writer.close()
+        import shutil
+        shutil.rmtree(out_dir, ignore_errors=True)
         host_boundary = {"host_frames_to_dense_field_ms": round(dense_ms, 2), "host_frames_to_cells_ms": round(cells_ms, 2),
                          "value_with_dense_download": round(blocks[0] / dense_ms / 1e3, 3),
                          "value_with_cells_download": round(blocks[0] / cells_ms / 1e3, 3), "unit": "Mblocks/s",
-                         "note": "upload of the two frames, padding + pyramid on the GPU, estimate, download; host buffers pinned"}
+                         "end_to_end_ms": round(sync_ms, 2), "end_to_end_async_writer_ms": round(async_ms, 2),
+                         "value_end_to_end": round(blocks[0] / async_ms / 1e3, 3),
+                         "flo_bytes": 12 + 8 * w * h, "flo_files_identical": same_file,
+                         "note": "per pair: upload of the two frames (pinned), padding + pyramid on the GPU, estimate, download "
+                                 "(pinned); end_to_end adds stripping the padding and Flow::WriteFlowFile to a tmpfs file, "
+                                 "synchronously / on the writer thread beside the next pair"}
 
     # per-kernel timing with HIP events on the ctx stream (eager launches, same kernels and data)
     prof = None
@@ -296,6 +332,10 @@ def main():
         search_ms = prof["search_ms"] / levels
         achieved = search_bytes / (search_ms * 1e-3) / 1e9
         absdiff = sum(blocks) * (2 * R + 1) ** 2 * block * block / levels
+        tabs = absdiff / (search_ms * 1e-3) / 1e12
+        seen, viol = C.c_int(), C.c_int()
+        _capi.check(_capi.lib().bbme_probe_xcd(local_rank, C.byref(seen), C.byref(viol)))
+        xcd_check = {"xcds_seen": seen.value, "workgroups_off_their_residue_class": viol.value, "of": 4096}
         out = {
             "metric": "Mblocks/s (16x16, +-32 full search)", "value": round(value, 4), "unit": "Mblocks/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -307,17 +347,24 @@ def main():
                        "multi_gpu": ("one pair per GPU; int16 cell grids gathered on rank 0 over RCCL and expanded there to "
                                      "the dense .flo fields, on a second stream beside the next step's estimate")
                                     if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "k_search_fast<%d> (mean of the %d per-level launches)" % (block, levels),
+            # contract fields (achieved / peak / unit / frac / traffic) are the HBM figures; what BINDS the kernel is the issue
+            # rate of the integer SAD instructions, priced in `binding` against the chip's spec rate
+            "roofline": {"bound": "valu", "kernel": "k_search_fast<%d> (mean of the %d per-level launches)" % (block, levels),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(levels),
                          "algorithmic_bytes_per_launch": round(search_bytes),
                          "avg_launch_ms": round(search_ms, 5),
-                         "note": "kernel is bound by the issue rate of the integer SAD instructions, not by HBM (SURVEY 8d)",
-                         "valu_sad": {"achieved_Tabsdiff_s": round(absdiff / (search_ms * 1e-3) / 1e12, 3),
-                                      "peak_Tabsdiff_s": round(qsad_peak, 2),
-                                      "frac": round(absdiff / (search_ms * 1e-3) / 1e12 / qsad_peak, 5),
-                                      "peak_source": "measured on this device by bbme_probe_rates: v_qsad_pk_u16_u8 issue rate "
-                                                     "x 16 abs-diff per lane (v_sad_u8: %.1f T/s)" % sad_peak}},
+                         "binding": {"unit": "T abs-diff/s", "achieved": round(tabs, 3), "peak": VALU_SAD_PEAK_T,
+                                     "frac": round(tabs / VALU_SAD_PEAK_T, 5),
+                                     "peak_source": "spec: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz x 4 abs-diff per v_sad_u8 lane-op",
+                                     "measured_ceilings_Tabsdiff_s": {"v_qsad_pk_u16_u8": round(qsad_peak, 2), "v_sad_u8": round(sad_peak, 2)},
+                                     "frac_of_measured_qsad_ceiling": round(tabs / qsad_peak, 5),
+                                     "level0_launch": {"ms": round(prof["search_level0_ms"], 4),
+                                                       "achieved": round(blocks[0] * (2 * R + 1) ** 2 * block * block / (prof["search_level0_ms"] * 1e-3) / 1e12, 3)}},
+                         "xcd_round_robin": xcd_check},
+            "search_only": {"value": round(sum(blocks) / (prof["search_ms"] * 1e-3) / 1e6, 3), "unit": "Mblocks/s",
+                            "blocks": sum(blocks), "ms": round(prof["search_ms"], 4),
+                            "note": "the %d search launches alone (all-level block count), from the eager HIP-event pass" % levels},
             "device_ms": {k: round(val, 4) for k, val in prof.items()},
         }
         # the regulariser takes most of the step although it is 2 % of the arithmetic: every sweep is a

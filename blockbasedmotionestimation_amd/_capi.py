@@ -52,6 +52,10 @@ SIGNATURES = {
     "bbme_resize_x4_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "bbme_flo_read": (C.c_int, [C.c_char_p, _P(C.c_int), _P(C.c_int), _P(_P(C.c_float))]),
     "bbme_flo_write": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_void_p]),
+    "bbme_flo_writer_create": (C.c_int, [_P(C.c_void_p)]),
+    "bbme_flo_writer_submit": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "bbme_flo_writer_wait": (C.c_int, [C.c_void_p]),
+    "bbme_flo_writer_destroy": (C.c_int, [C.c_void_p]),
     "bbme_calculate_mse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _P(C.c_double)]),
     "bbme_motion_to_color": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, _P(C.c_float)]),
     "bbme_ppm_write_bgr": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_void_p]),
@@ -89,6 +93,9 @@ SIGNATURES = {
     "bbme_get_timings": (C.c_int, [_ctx] + [_P(C.c_float)] * 5),
     "bbme_probe_rates": (C.c_int, [C.c_int, _P(C.c_double)]),
     "bbme_probe_latency": (C.c_int, [C.c_int, _P(C.c_ulonglong)]),
+    "bbme_probe_xcd": (C.c_int, [C.c_int, _P(C.c_int), _P(C.c_int)]),
+    "bbme_set_speculation": (C.c_int, [_ctx, C.c_int]),
+    "bbme_wait_for_stream": (C.c_int, [_ctx, C.c_void_p]),
     "bbme_calibrate_read": (C.c_int, [C.c_int, C.c_uint, C.c_int]),
     "bbme_selftest_isa": (C.c_int, [C.c_int, _P(C.c_int)]),
 }

@@ -69,6 +69,7 @@ struct bbme_ctx {
     uint32_t own_pitch = 0;                       // transposed layout: 32 residue classes of own_pitch words
     uint32_t *counters = nullptr;                 // 64 words (RegArgs::counters)
     bool frames_set = false;
+    double *epe_scratch = nullptr;                // partial sums + counts of bbme_calculate_mse_device (allocated on first use)
     int solve_waves = 4;                          // waves per solver workgroup (1, 2 or 4); BBME_SOLVE_WAVES
     int solve_wgs = 256;                          // most workgroups of k_reg_solve (4 independent waves each): one wave per SIMD
     int xcd_remap = 1;                            // XCD-aware block order in k_search_fast; BBME_XCD_REMAP
@@ -531,6 +532,7 @@ int bbme_destroy(bbme_ctx *c)
         (void)hipFree(L.rank_of); (void)hipFree(L.tasks); (void)hipFree(L.rounds);
     }
     (void)hipFree(c->flow);
+    (void)hipFree(c->epe_scratch);
     (void)hipFree(c->list[0]); (void)hipFree(c->list[1]);
     (void)hipFree(c->own);
     (void)hipFree(c->flags[0]); (void)hipFree(c->flags[1]);
@@ -555,6 +557,30 @@ int bbme_set_stream(bbme_ctx *c, void *hip_stream)
         HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
     }
+    return BBME_OK;
+}
+
+int bbme_set_speculation(bbme_ctx *c, int enabled)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (c->speculate == (enabled != 0)) return BBME_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    drop_graph(c);                                   // the launch sequence changes
+    c->speculate = enabled != 0;
+    return BBME_OK;
+}
+
+int bbme_wait_for_stream(bbme_ctx *c, void *producer_stream)
+{
+    if (int rc = check_ctx(c)) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, static_cast<hipStream_t>(producer_stream));
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, ev, 0);
+    (void)hipEventDestroy(ev);                      // released once the recorded work has completed
+    if (e != hipSuccess) return bbme::fail(BBME_ERR_HIP, "bbme_wait_for_stream: %s", hipGetErrorString(e));
     return BBME_OK;
 }
 
@@ -769,8 +795,8 @@ int bbme_calculate_mse_device(bbme_ctx *c, const float *d_gtruth, int gt_width, 
     constexpr int kMaxGroups = 512;
     const long long n = (long long)gt_width * gt_height;
     const int groups = (int)std::min<long long>(kMaxGroups, (n + 255) / 256);
-    double *d_sum = nullptr;
-    HIP_TRY(hipMalloc(&d_sum, kMaxGroups * (sizeof(double) + sizeof(unsigned long long))));
+    if (!c->epe_scratch) HIP_TRY(hipMalloc(&c->epe_scratch, kMaxGroups * (sizeof(double) + sizeof(unsigned long long))));
+    double *d_sum = c->epe_scratch;
     unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>(d_sum + kMaxGroups);
     hipLaunchKernelGGL(k_epe, dim3(groups), dim3(256), 0, c->stream, L.cur_grid, L.width / 2,
                        c->geom.pad_x, c->geom.pad_y, scale, d_gtruth, gt_width, gt_height, d_sum, d_cnt);
@@ -779,8 +805,6 @@ int bbme_calculate_mse_device(bbme_ctx *c, const float *d_gtruth, int gt_width, 
     hipError_t err = hipGetLastError();
     if (err == hipSuccess) err = hipMemcpyAsync(h_sum.data(), d_sum, groups * sizeof(double), hipMemcpyDeviceToHost, c->stream);
     if (err == hipSuccess) err = hipMemcpyAsync(h_cnt.data(), d_cnt, groups * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
-    if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_sum);
     if (err != hipSuccess) return bbme::fail(BBME_ERR_HIP, "bbme_calculate_mse_device: %s", hipGetErrorString(err));
     if (int rc = check_converged(c)) return rc;
     double error = 0;
@@ -946,6 +970,31 @@ int bbme_probe_latency(int device, unsigned long long *out9)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out9, out, 9 * 8, hipMemcpyDeviceToHost));
     (void)hipFree(buf); (void)hipFree(out);
+    return BBME_OK;
+}
+
+int bbme_probe_xcd(int device, int *xcds_seen, int *violations)
+{
+    if (!xcds_seen || !violations) return bbme::fail(BBME_ERR_INVALID, "null output");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return bbme::fail(BBME_ERR_HIP, "no HIP device %d", device);
+    HIP_TRY(hipSetDevice(device));
+    const int n = 4096;
+    std::vector<uint32_t> host(n);
+    uint32_t *d = nullptr;
+    HIP_TRY(hipMalloc(&d, n * 4));
+    hipLaunchKernelGGL(k_probe_xcc, dim3(n), dim3(64), 0, 0, d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(host.data(), d, n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    uint32_t seen = 0;
+    *violations = 0;
+    for (int b = 0; b < n; ++b) {
+        seen |= 1u << host[b];
+        if (host[b] != host[b & 7]) ++*violations;
+    }
+    *xcds_seen = __builtin_popcount(seen);
     return BBME_OK;
 }
 

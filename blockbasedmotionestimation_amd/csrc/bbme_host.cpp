@@ -10,6 +10,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
 
 namespace bbme {
 
@@ -544,5 +549,101 @@ int bbme_search_plan_host(int range, int block_size, uint32_t *rounds, int round
 }
 
 void bbme_free(void *p) { free(p); }
+
+// ---- asynchronous .flo writer: Flow::WriteFlowFile (rw_flow.cpp:139-200) on a worker thread ----
+// The caller hands over a window of a (pinned) host buffer -- typically the padded field bbme_get_flow_host filled,
+// with the padding stripped as main_class.cpp:63-70 does -- and goes on with the next pair; the worker writes the
+// same bytes WriteFlowFile would ("PIEH", width, height, rows of interleaved u, v).  The buffer must stay untouched
+// until bbme_flo_writer_wait returns.
+struct bbme_flo_writer {
+    struct Job { std::string name; int width, height; const float *data; size_t pitch_floats; };
+    std::mutex mu;
+    std::condition_variable cv_job, cv_idle;
+    std::deque<Job> jobs;
+    bool busy = false, stop = false;
+    int status = BBME_OK;
+    std::string error;
+    std::thread worker;
+};
+
+static void flo_writer_main(bbme_flo_writer *w)
+{
+    std::unique_lock<std::mutex> lk(w->mu);
+    for (;;) {
+        w->cv_job.wait(lk, [&] { return w->stop || !w->jobs.empty(); });
+        if (w->jobs.empty()) return;
+        bbme_flo_writer::Job job = w->jobs.front();
+        w->jobs.pop_front();
+        w->busy = true;
+        lk.unlock();
+        bool ok = false;
+        if (FILE *f = fopen(job.name.c_str(), "wb")) {
+            ok = fwrite(bbme::kTagString, 1, 4, f) == 4 && fwrite(&job.width, 4, 1, f) == 1 && fwrite(&job.height, 4, 1, f) == 1;
+            const size_t row = (size_t)job.width * 2;
+            if (job.pitch_floats == row) ok = ok && fwrite(job.data, sizeof(float), row * job.height, f) == row * job.height;
+            else
+                for (int y = 0; ok && y < job.height; ++y)
+                    ok = fwrite(job.data + (size_t)y * job.pitch_floats, sizeof(float), row, f) == row;
+            ok = (fclose(f) == 0) && ok;
+        }
+        lk.lock();
+        if (!ok && w->status == BBME_OK) { w->status = BBME_ERR_IO; w->error = "WriteFlowFile: problem writing " + job.name; }
+        w->busy = false;
+        if (w->jobs.empty()) w->cv_idle.notify_all();
+    }
+}
+
+int bbme_flo_writer_create(bbme_flo_writer **out)
+{
+    if (!out) return bbme::fail(BBME_ERR_INVALID, "bbme_flo_writer_create: null output");
+    bbme_flo_writer *w = new bbme_flo_writer();
+    w->worker = std::thread(flo_writer_main, w);
+    *out = w;
+    return BBME_OK;
+}
+
+int bbme_flo_writer_submit(bbme_flo_writer *w, const char *filename, int width, int height, const float *data,
+                           int pitch_pixels)
+{
+    if (!w || !data || width < 1 || height < 1 || pitch_pixels < width)
+        return bbme::fail(BBME_ERR_INVALID, "bbme_flo_writer_submit: bad arguments");
+    if (!filename) return bbme::fail(BBME_ERR_IO, "WriteFlowFile: empty filename");
+    const char *dot = strrchr(filename, '.');
+    if (!dot) return bbme::fail(BBME_ERR_IO, "WriteFlowFile: extension required in filename");
+    if (strcmp(dot, ".flo") != 0) return bbme::fail(BBME_ERR_IO, "WriteFlowFile: filename should have extension '.flo'");
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->jobs.push_back({filename, width, height, data, (size_t)pitch_pixels * 2});
+    }
+    w->cv_job.notify_one();
+    return BBME_OK;
+}
+
+int bbme_flo_writer_wait(bbme_flo_writer *w)
+{
+    if (!w) return bbme::fail(BBME_ERR_INVALID, "bbme_flo_writer_wait: null writer");
+    std::unique_lock<std::mutex> lk(w->mu);
+    w->cv_idle.wait(lk, [&] { return w->jobs.empty() && !w->busy; });
+    if (w->status != BBME_OK) {
+        const int st = w->status;
+        const std::string msg = w->error;
+        w->status = BBME_OK; w->error.clear();
+        return bbme::fail(st, "%s", msg.c_str());
+    }
+    return BBME_OK;
+}
+
+int bbme_flo_writer_destroy(bbme_flo_writer *w)
+{
+    if (!w) return BBME_OK;
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->stop = true;
+    }
+    w->cv_job.notify_all();
+    w->worker.join();                       // finishes the queued files first
+    delete w;
+    return BBME_OK;
+}
 
 }  // extern "C"

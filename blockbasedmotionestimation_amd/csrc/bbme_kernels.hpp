@@ -1343,6 +1343,14 @@ __global__ void k_probe_latency(uint32_t *buf, uint32_t nwords, unsigned long lo
     out[8] = idx;
 }
 
+// Which XCD a workgroup runs on (HW_REG_XCC_ID, bits 3:0).  The kernels only ASSUME that workgroups b and b + 8 share an
+// XCD (round-robin dispatch) when they give every residue class of blockIdx.x mod 8 a contiguous part of the raster;
+// bbme_probe_xcd checks that assumption on the device.  Speed only: no result depends on it.
+__global__ void k_probe_xcc(uint32_t *out)
+{
+    if (threadIdx.x == 0) out[blockIdx.x] = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;
+}
+
 // unaligned global loads: dword / dwordx2 / dwordx4 at arbitrary byte addresses
 struct __attribute__((packed, aligned(1))) ua_u32 { uint32_t v; };
 struct __attribute__((packed, aligned(1))) ua_u32x2 { uint32_t v[2]; };

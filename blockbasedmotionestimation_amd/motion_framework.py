@@ -85,8 +85,15 @@ class MF:
         assert image1.is_cuda and image2.is_cuda and image1.dtype.itemsize == 1
         assert image1.stride(1) == 1 and image2.stride(1) == 1 and image1.stride(0) == image2.stride(0)
         self._torch_frames = (image1, image2)
+        # the tensors may still be being written by work on torch's current stream: order the context's stream behind it
+        import torch
+        _capi.check(self._lib.bbme_wait_for_stream(self._ctx, C.c_void_p(torch.cuda.current_stream(image1.device).cuda_stream)))
         _capi.check(self._lib.bbme_set_frames_device(self._ctx, image1.data_ptr(), image2.data_ptr(),
                                                      image1.stride(0)))
+
+    def set_speculation(self, enabled):
+        """Speculative search of the next finer level beside a level's late sweeps (bbme_set_speculation); same result."""
+        _capi.check(self._lib.bbme_set_speculation(self._ctx, int(bool(enabled))))
 
     def set_stream(self, hip_stream_handle):
         _capi.check(self._lib.bbme_set_stream(self._ctx, C.c_void_p(hip_stream_handle)))

@@ -74,3 +74,44 @@ def subsample_div4(flow_padded, pad_x, pad_y, out_width, out_height):
     _capi.check(_capi.lib().bbme_subsample_div4(f.ctypes.data, f.shape[1], f.shape[0], pad_x, pad_y,
                                                 out.ctypes.data, out_width, out_height))
     return out
+
+
+class FlowWriter:
+    """Flow::WriteFlowFile on a worker thread (bbme_flo_writer_*): submit() returns at once, the file is written while
+    the next pair is being estimated.  The array handed to submit() must stay alive and untouched until wait()."""
+
+    def __init__(self):
+        self._w = C.c_void_p()
+        _capi.check(_capi.lib().bbme_flo_writer_create(C.byref(self._w)))
+        self._keep = []
+
+    def submit(self, flow_padded, filename, pad_x=0, pad_y=0, width=None, height=None):
+        """The (height, width) window at (pad_y, pad_x) of a C-contiguous float32 (H, W, 2) field (default: all of it)."""
+        f = flow_padded
+        if f.dtype != np.float32 or f.ndim != 3 or f.shape[2] != 2 or not f.flags.c_contiguous:
+            raise _capi.BbmeError(_capi.ERR_INVALID, "FlowWriter.submit: C-contiguous float32 (H, W, 2) field expected")
+        width = f.shape[1] - pad_x if width is None else width
+        height = f.shape[0] - pad_y if height is None else height
+        if pad_x < 0 or pad_y < 0 or pad_x + width > f.shape[1] or pad_y + height > f.shape[0]:
+            raise _capi.BbmeError(_capi.ERR_INVALID, "FlowWriter.submit: window outside the field")
+        self._keep.append(f)
+        ptr = f.ctypes.data + 8 * (pad_y * f.shape[1] + pad_x)
+        _capi.check(_capi.lib().bbme_flo_writer_submit(self._w, os.fsencode(filename), width, height, C.c_void_p(ptr), f.shape[1]))
+
+    def wait(self):
+        try:
+            _capi.check(_capi.lib().bbme_flo_writer_wait(self._w))
+        finally:
+            self._keep.clear()
+
+    def close(self):
+        if self._w:
+            _capi.lib().bbme_flo_writer_destroy(self._w)
+            self._w = C.c_void_p()
+            self._keep.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

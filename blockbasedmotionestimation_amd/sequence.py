@@ -163,6 +163,8 @@ def estimate_pairs_pipelined(pairs, search_size, block_size, device=None, in_fli
             if len(slots) < max(1, in_flight):
                 slots.append(MF(f1, f2, search_size, block_size, len(block_size), device=device))
                 slot = len(slots) - 1
+                if in_flight > 1:
+                    slots[slot].set_speculation(False)      # the other pairs in flight fill the chip already
             else:
                 slot = pending[0][0]
                 collect()

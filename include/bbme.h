@@ -72,6 +72,18 @@ int bbme_resize_x4_host(const uint8_t *src, int src_width, int src_height, uint8
 int bbme_flo_read(const char *filename, int *width, int *height, float **data);
 /* Flow::WriteFlowFile (rw_flow.cpp:139-200). */
 int bbme_flo_write(const char *filename, int width, int height, const float *data);
+/* Flow::WriteFlowFile on a worker thread (the reference's writer, rw_flow.cpp:139-200, has no caller and
+ * is synchronous): submit hands over `height` rows of `width` (u, v) pairs starting at `data`, consecutive rows
+ * `pitch_pixels` pixels apart -- e.g. the unpadded window of the padded field bbme_get_flow_host left in pinned memory:
+ * data = flow + 2 * (pad_y * padded_width + pad_x), pitch_pixels = padded_width (main_class.cpp:63-70) -- and returns at
+ * once; files are written in submission order, byte for byte what bbme_flo_write produces.  The memory must stay
+ * untouched until bbme_flo_writer_wait returns, which also reports the first I/O error since the last wait. */
+typedef struct bbme_flo_writer bbme_flo_writer;
+int bbme_flo_writer_create(bbme_flo_writer **out);
+int bbme_flo_writer_submit(bbme_flo_writer *w, const char *filename, int width, int height, const float *data,
+                           int pitch_pixels);
+int bbme_flo_writer_wait(bbme_flo_writer *w);
+int bbme_flo_writer_destroy(bbme_flo_writer *w);
 /* Flow::CalculateMSE (rw_flow.cpp:309-332): mean end-point error over known GT pixels. */
 int bbme_calculate_mse(const float *gtruth, const float *flow, int width, int height, double *out);
 /* Flow::MotionToColor (rw_flow.cpp:202-249, with computeColor :251-275 and makecolorwheel :277-300):
@@ -116,6 +128,16 @@ int bbme_set_frames_host(bbme_ctx *ctx, const uint8_t *image1, const uint8_t *im
 /* Same constructor for frames already resident in HBM (unpadded, width x height):
  * zero padding and the whole pyrDown cascade run as HIP kernels on the ctx stream. */
 int bbme_set_frames_device(bbme_ctx *ctx, const uint8_t *d_image1, const uint8_t *d_image2, int pitch);
+/* Scheduling option (default on; BBME_SPECULATE=0 turns the default off): bbme_estimate starts the search of every level
+ * but the coarsest on a second stream beside the coarser level's late regulariser sweeps, predicting from that level's grid
+ * as it stands, and afterwards searches again the blocks whose prediction those sweeps changed.  Same field, bit for bit;
+ * shorter single pairs (the late sweeps leave most of the chip idle).  Turn it off when several contexts keep the chip
+ * busy anyway (sequences with pairs in flight). */
+int bbme_set_speculation(bbme_ctx *ctx, int enabled);
+/* Orders the ctx stream behind everything enqueued so far on another HIP stream of the same device (NULL = the default
+ * stream): call it before bbme_set_frames_device when the frames were produced by asynchronous work on that stream.
+ * Without it the caller must have synchronised the producer itself. */
+int bbme_wait_for_stream(bbme_ctx *ctx, void *producer_stream);
 /* Direct access to the ctx-owned padded planes of a level (device pointers, pitch ==
  * level width) so a caller can fill or inspect them in place. */
 int bbme_level_planes_device(bbme_ctx *ctx, int level, uint8_t **d_image1, uint8_t **d_image2);
@@ -192,6 +214,11 @@ int bbme_probe_rates(int device, double *gops);
  * chip: out[2k] = shader cycles per operation, out[2k+1] = 10 ns ticks for 256 operations, for
  * k = 0 plain load, 1 agent-scope load, 2 returning atomic, 3 agent-scope store + drain. */
 int bbme_probe_latency(int device, unsigned long long *out9);
+
+/* Checks on the device what the kernels' XCD-aware block orders assume: that workgroups b and b + 8 of a launch run on
+ * the same XCD (HW_REG_XCC_ID read by 4096 workgroups).  xcds_seen = distinct XCDs, violations = workgroups whose XCD
+ * differs from that of workgroup b mod 8.  Speed only -- no result depends on the placement. */
+int bbme_probe_xcd(int device, int *xcds_seen, int *violations);
 
 /* Profiling aid: launches a kernel that reads `mbytes` MiB exactly once with one aligned dword per
  * lane (the access shape of the search kernel's window staging), `repeats` times, so that the
