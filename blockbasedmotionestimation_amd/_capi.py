@@ -66,6 +66,7 @@ SIGNATURES = {
     "bbme_create": (C.c_int, [_P(Params), C.c_int, C.c_int, C.c_int, _P(_ctx)]),
     "bbme_destroy": (C.c_int, [_ctx]),
     "bbme_set_stream": (C.c_int, [_ctx, C.c_void_p]),
+    "bbme_get_stream": (C.c_int, [_ctx, _P(C.c_void_p)]),
     "bbme_get_geometry": (C.c_int, [_ctx] + [_P(C.c_int)] * 4),
     "bbme_level_geometry": (C.c_int, [_ctx, C.c_int] + [_P(C.c_int)] * 4),
     "bbme_set_frames_host": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int]),
@@ -94,6 +95,7 @@ SIGNATURES = {
     "bbme_probe_rates": (C.c_int, [C.c_int, _P(C.c_double)]),
     "bbme_probe_latency": (C.c_int, [C.c_int, _P(C.c_ulonglong)]),
     "bbme_probe_xcd": (C.c_int, [C.c_int, _P(C.c_int), _P(C.c_int)]),
+    "bbme_set_search_mode": (C.c_int, [_ctx, C.c_int]),
     "bbme_set_speculation": (C.c_int, [_ctx, C.c_int]),
     "bbme_wait_for_stream": (C.c_int, [_ctx, C.c_void_p]),
     "bbme_calibrate_read": (C.c_int, [C.c_int, C.c_uint, C.c_int]),

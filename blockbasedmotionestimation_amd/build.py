@@ -14,9 +14,11 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libbbme.so")
 CLI = os.path.join(PKG, "bbme_cli")
+RCCL_LIB = os.path.join(PKG, "libbbme_rccl.so")
+SEQ = os.path.join(PKG, "bbme_seq")
 SOURCES = ["bbme_host.cpp", "bbme_device.hip"]
 HEADERS = ["bbme_internal.hpp", "bbme_kernels.hpp", "motion_framework.hpp", "rw_flow.hpp", "bbme_main.cpp",
-           os.path.join(ROOT, "include", "bbme.h")]
+           "bbme_rccl.cpp", "bbme_seq_main.cpp", os.path.join(ROOT, "include", "bbme.h"), os.path.join(ROOT, "include", "bbme_rccl.h")]
 ARCH = "gfx950"
 
 
@@ -28,7 +30,7 @@ def _hipcc():
 
 
 def needs_build():
-    if not os.path.exists(LIB) or not os.path.exists(CLI):
+    if not all(os.path.exists(f) for f in (LIB, CLI, RCCL_LIB, SEQ)):
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + \
@@ -57,6 +59,18 @@ def build(force=False, verbose=False):
         print(" ".join(cli))
     subprocess.check_call(cli)
     os.replace(CLI + ".tmp", CLI)
+    # the multi-GPU sequence without torch: the gather over RCCL as a small C-ABI library on top of libbbme.so, and its driver
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    host = ["g++", "-std=c++17", "-O2", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+            "-I", os.path.join(rocm, "include")]
+    link = ["-L", PKG, "-lbbme", "-L", os.path.join(rocm, "lib"), "-lrccl", "-lamdhip64", "-Wl,-rpath,$ORIGIN",
+            "-Wl,-rpath," + os.path.join(rocm, "lib")]
+    for cmd, dst in ((host + ["-fPIC", "-shared", os.path.join(CSRC, "bbme_rccl.cpp"), "-o", RCCL_LIB + ".tmp"] + link, RCCL_LIB),
+                     (host + [os.path.join(CSRC, "bbme_seq_main.cpp"), "-o", SEQ + ".tmp", "-lbbme_rccl", "-lpthread"] + link, SEQ)):
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        os.replace(dst + ".tmp", dst)
     return LIB
 
 

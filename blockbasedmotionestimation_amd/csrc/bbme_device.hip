@@ -73,6 +73,7 @@ struct bbme_ctx {
     int solve_waves = 4;                          // waves per solver workgroup (1, 2 or 4); BBME_SOLVE_WAVES
     int solve_wgs = 256;                          // most workgroups of k_reg_solve (4 independent waves each): one wave per SIMD
     int xcd_remap = 1;                            // XCD-aware block order in k_search_fast; BBME_XCD_REMAP
+    bool raster_search = false;                   // MF::find_min_block (:246-294) instead of the spiral search; bbme_set_search_mode
     bool force_generic_search = false;            // BBME_GENERIC_SEARCH=1: use k_search_generic everywhere
     bool use_graph = true;
     bool speculate = true;                        // overlap every level's search with the coarser level's late sweeps; BBME_SPECULATE
@@ -82,7 +83,7 @@ struct bbme_ctx {
     hipGraphExec_t graph_exec = nullptr;
     bool profiling = false;
     float t_total = 0, t_search = 0, t_reg = 0, t_expand = 0, t_search0 = 0;
-    std::vector<uint8_t> host_a, host_b;          // staging for bbme_set_frames_host
+    uint8_t *raw[2] = {nullptr, nullptr};         // bbme_set_frames_host: the unpadded frames in HBM (allocated on first use)
 };
 
 namespace {
@@ -196,13 +197,14 @@ int launch_search(bbme_ctx *c, int level, int mode = kSearchPlain, hipStream_t s
     Level &L = c->lv[level];
     if (!stream) stream = c->stream;
     int rc;
-    if (L.fast && !c->force_generic_search) {
+    if (L.fast && !c->force_generic_search && !c->raster_search) {
         rc = launch_search_fast(c, level, mode, stream, lds_floor);
     } else {
         SearchArgs a{};
         a.image1 = L.img1; a.image2 = L.img2;
         a.width = L.width; a.height = L.height;
         a.range = L.range; a.ncand = L.ncand; a.spiral = L.spiral;
+        a.raster = c->raster_search ? 1 : 0;
         if ((rc = set_prediction_source(c, level, mode, a))) return rc;
         a.out = L.small[0];
         a.cols = L.width / L.block;
@@ -533,6 +535,7 @@ int bbme_destroy(bbme_ctx *c)
     }
     (void)hipFree(c->flow);
     (void)hipFree(c->epe_scratch);
+    (void)hipFree(c->raw[0]); (void)hipFree(c->raw[1]);
     (void)hipFree(c->list[0]); (void)hipFree(c->list[1]);
     (void)hipFree(c->own);
     (void)hipFree(c->flags[0]); (void)hipFree(c->flags[1]);
@@ -560,6 +563,18 @@ int bbme_set_stream(bbme_ctx *c, void *hip_stream)
     return BBME_OK;
 }
 
+int bbme_set_search_mode(bbme_ctx *c, int mode)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (mode != BBME_SEARCH_SPIRAL && mode != BBME_SEARCH_RASTER) return bbme::fail(BBME_ERR_INVALID, "search mode %d", mode);
+    if (c->raster_search == (mode == BBME_SEARCH_RASTER)) return BBME_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    drop_graph(c);                                   // other kernels in the launch sequence
+    c->raster_search = mode == BBME_SEARCH_RASTER;
+    return BBME_OK;
+}
+
 int bbme_set_speculation(bbme_ctx *c, int enabled)
 {
     if (int rc = check_ctx(c)) return rc;
@@ -581,6 +596,14 @@ int bbme_wait_for_stream(bbme_ctx *c, void *producer_stream)
     if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, ev, 0);
     (void)hipEventDestroy(ev);                      // released once the recorded work has completed
     if (e != hipSuccess) return bbme::fail(BBME_ERR_HIP, "bbme_wait_for_stream: %s", hipGetErrorString(e));
+    return BBME_OK;
+}
+
+int bbme_get_stream(bbme_ctx *c, void **hip_stream)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (!hip_stream) return bbme::fail(BBME_ERR_INVALID, "null output");
+    *hip_stream = c->stream;
     return BBME_OK;
 }
 
@@ -610,24 +633,17 @@ int bbme_set_frames_host(bbme_ctx *c, const uint8_t *image1, const uint8_t *imag
     if (int rc = check_ctx(c)) return rc;
     if (!image1 || !image2 || pitch < c->geom.width) return bbme::fail(BBME_ERR_INVALID, "bbme_set_frames_host: bad arguments");
     HIP_TRY(hipSetDevice(c->device));
+    // the frames as they are go to HBM; zero border and pyrDown cascade run there (bbme_set_frames_device) -- the same
+    // integers as bbme_pad_zero_host / bbme_pyr_down_host produce, without 18 ms of single-threaded host filtering at 4K
     const Geometry &g = c->geom;
+    const size_t bytes = (size_t)g.width * g.height;
     const uint8_t *src[2] = {image1, image2};
-    for (int which = 0; which < 2; ++which) {
-        c->host_a.resize((size_t)g.padded_width * g.padded_height);
-        pad_zero(src[which], g.width, g.height, pitch, g.pad_x, g.pad_y, c->host_a.data());
-        for (size_t l = 0; l < c->lv.size(); ++l) {
-            Level &L = c->lv[l];
-            uint8_t *dst = which ? L.img2 : L.img1;
-            HIP_TRY(hipMemcpyAsync(dst, c->host_a.data(), (size_t)L.width * L.height, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            if (l + 1 < c->lv.size()) {
-                c->host_b.resize((size_t)(L.width / 2) * (L.height / 2));
-                pyr_down(c->host_a.data(), L.width, L.height, c->host_b.data());
-                c->host_a.swap(c->host_b);
-            }
-        }
+    for (int i = 0; i < 2; ++i) {
+        if (!c->raw[i]) HIP_TRY(hipMalloc(&c->raw[i], bytes + 64));
+        HIP_TRY(hipMemcpy2DAsync(c->raw[i], g.width, src[i], pitch, g.width, g.height, hipMemcpyHostToDevice, c->stream));
     }
-    c->frames_set = true;
+    if (int rc = bbme_set_frames_device(c, c->raw[0], c->raw[1], g.width)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));        // the caller may re-use its buffers
     return BBME_OK;
 }
 
@@ -637,18 +653,21 @@ int bbme_set_frames_device(bbme_ctx *c, const uint8_t *d_image1, const uint8_t *
     if (!d_image1 || !d_image2 || pitch < c->geom.width) return bbme::fail(BBME_ERR_INVALID, "bbme_set_frames_device: bad arguments");
     HIP_TRY(hipSetDevice(c->device));
     const Geometry &g = c->geom;
-    const uint8_t *src[2] = {d_image1, d_image2};
-    for (int which = 0; which < 2; ++which) {
-        Level &L0 = c->lv[0];
-        uint8_t *p0 = which ? L0.img2 : L0.img1;
-        const long long dws = (long long)(L0.width / 4) * L0.height;
-        hipLaunchKernelGGL(k_pad_zero, dim3((unsigned)((dws + 255) / 256)), dim3(256), 0, c->stream,
-                           src[which], g.width, g.height, pitch, g.pad_x, g.pad_y, p0, L0.width, L0.height);
-        for (size_t l = 1; l < c->lv.size(); ++l) {
-            Level &P = c->lv[l - 1], &L = c->lv[l];
-            const long long px = (long long)L.width * L.height;
-            hipLaunchKernelGGL(k_pyr_down, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, c->stream,
-                               which ? P.img2 : P.img1, P.width, P.height, which ? L.img2 : L.img1);
+    // both frames per launch: zero border into the level-0 planes, then the pyrDown cascade
+    Level &L0 = c->lv[0];
+    PlanePair pp{{d_image1, d_image2}, {L0.img1, L0.img2}};
+    const long long chunks = (long long)((L0.width + 15) / 16) * L0.height;
+    hipLaunchKernelGGL(k_pad_zero, dim3((unsigned)((chunks + 255) / 256), 2), dim3(256), 0, c->stream,
+                       pp, g.width, g.height, pitch, g.pad_x, g.pad_y, L0.width, L0.height);
+    for (size_t l = 1; l < c->lv.size(); ++l) {
+        Level &P = c->lv[l - 1], &L = c->lv[l];
+        PlanePair q{{P.img1, P.img2}, {L.img1, L.img2}};
+        if (P.width % 8 == 0) {
+            const long long n = (long long)(L.width / 4) * L.height;
+            hipLaunchKernelGGL(k_pyr_down4, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, c->stream, q, P.width, P.height);
+        } else {
+            const long long n = (long long)L.width * L.height;
+            hipLaunchKernelGGL(k_pyr_down, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, c->stream, q, P.width, P.height);
         }
     }
     HIP_TRY(hipGetLastError());

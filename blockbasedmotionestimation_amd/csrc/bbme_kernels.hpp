@@ -39,6 +39,7 @@ struct SearchArgs {
     int coarse_block;           // B_{l+1}
     int coarse_cell_shift;      // 1: the final 2x2-cell grid; log2(B_{l+1}): the grid after the sweeps at B_{l+1} (speculation)
     int mode;                   // kSearchPlain / kSearchSpeculative / kSearchFixup (see search_prediction)
+    int raster;                 // 1: MF::find_min_block (:246-294) instead of find_min_block_spiral
     mv_t *pred;                 // per block of this level: the coarse MV a speculative search started from
     mv_t *out;                  // (H/B) x (W/B)
     int cols;                   // W / B
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(64) void k_search_generic(SearchArgs a)
     const int u = 2 * mv_x(m), v = 2 * mv_y(m);
     const int px = j + u, py = i + v;                      // :233-234
     mv_t *dst = a.out + (size_t)br * a.cols + bc;
-    if (px < 0 || py < 0 || px + B > a.width || py + B > a.height) {   // :304-310 -> zero MV
+    if (!a.raster && (px < 0 || py < 0 || px + B > a.width || py + B > a.height)) {   // :304-310 -> zero MV
         if (lane == 0) *dst = 0;
         return;
     }
@@ -108,12 +109,8 @@ __global__ __launch_bounds__(64) void k_search_generic(SearchArgs a)
     }
     __syncthreads();
 
-    uint32_t best_sad = 0xffffffffu, best_rank = 0xffffffffu;
-    for (int rank = lane; rank < a.ncand; rank += 64) {
-        const uint32_t s = a.spiral[rank];
-        const int dx = (int)(int16_t)(s & 0xffffu), dy = (int)(int16_t)(s >> 16);
-        const int cx = px + dx, cy = py + dy;
-        if (cx < 0 || cy < 0 || cx + B > a.width || cy + B > a.height) continue;   // :335 skipped
+    // SAD of the candidate at offset (dx, dy) from the prediction (its block lies inside the image)
+    auto candidate_sad = [&](int dx, int dy) {
         const int ox = dx + R + sh0;                       // byte offset inside an LDS row
         const int k0 = ox >> 2, sh = ox & 3;
         const uint32_t *wrow = win + (dy + R) * a.pitch_dw + k0;
@@ -130,6 +127,43 @@ __global__ __launch_bounds__(64) void k_search_generic(SearchArgs a)
             }
             wrow += a.pitch_dw;
         }
+        return sad;
+    };
+    if (a.raster) {
+        // MF::find_min_block (:246-294): every candidate of [-R, R]^2 whose block lies inside the image (the clamped loops
+        // of :260,262), no special case for a prediction outside it; winner = lowest SAD, then the smaller L1 distance
+        // to the block's own position (:276-281), then raster order (strict comparisons): one 64-bit key
+        const int side = 2 * R + 1;
+        unsigned long long best = ~0ull;
+        for (int idx = lane; idx < side * side; idx += 64) {
+            const int dy = idx / side - R, dx = idx % side - R;
+            const int cx = px + dx, cy = py + dy;
+            if (cx < 0 || cy < 0 || cx + B > a.width || cy + B > a.height) continue;
+            const uint32_t l1 = (uint32_t)(abs(cx - j) + abs(cy - i));
+            const unsigned long long key = ((unsigned long long)candidate_sad(dx, dy) << 32) | (l1 << 16) | (uint32_t)idx;
+            best = key < best ? key : best;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(best, o);
+            best = other < best ? other : best;
+        }
+        if (lane == 0) {
+            // no candidate inside the image: min_x, min_y keep the prediction (:251-252)
+            int dx = 0, dy = 0;
+            if (best != ~0ull) { const int idx = (int)(best & 0xffffu); dy = idx / side - R; dx = idx % side - R; }
+            *dst = mv_pack(u + dx, v + dy);
+        }
+        return;
+    }
+
+    uint32_t best_sad = 0xffffffffu, best_rank = 0xffffffffu;
+    for (int rank = lane; rank < a.ncand; rank += 64) {
+        const uint32_t s = a.spiral[rank];
+        const int dx = (int)(int16_t)(s & 0xffffu), dy = (int)(int16_t)(s >> 16);
+        const int cx = px + dx, cy = py + dy;
+        if (cx < 0 || cy < 0 || cx + B > a.width || cy + B > a.height) continue;   // :335 skipped
+        const uint32_t sad = candidate_sad(dx, dy);
         if (sad < best_sad) { best_sad = sad; best_rank = (uint32_t)rank; }         // strict :339
     }
     // wave reduction of (sad, rank), lexicographic
@@ -1196,25 +1230,42 @@ __global__ __launch_bounds__(256) void k_epe(const mv_t *cells, int cell_cols, i
 }
 
 // =======================================================================================
-// MF::MF on the GPU (motion_framework.cpp:57-61, 86-106): zero border and pyrDown cascade.
+// MF::MF on the GPU (motion_framework.cpp:57-61, 86-106): zero border and pyrDown cascade.  Both frames of the pair
+// in one launch (blockIdx.y).  Bandwidth-bound byte work: 16 bytes per thread for the border copy, four output pixels
+// per thread for pyrDown (dword loads, the 5-tap rows as v_dot4_u32_u8 on re-aligned dwords).
 // =======================================================================================
-__global__ __launch_bounds__(256) void k_pad_zero(const uint8_t *src, int width, int height, int pitch,
-                                                  int pad_x, int pad_y, uint8_t *dst, int pw, int ph)
+struct PlanePair { const uint8_t *src[2]; uint8_t *dst[2]; };
+
+struct __attribute__((packed, aligned(1))) ua_u128 { uint32_t v[4]; };
+
+__global__ __launch_bounds__(256) void k_pad_zero(PlanePair p, int width, int height, int pitch,
+                                                  int pad_x, int pad_y, int pw, int ph)
 {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;    // one output dword
-    const int dwpr = pw / 4;
-    if (t >= (long long)dwpr * ph) return;
-    const int y = (int)(t / dwpr), x0 = (int)(t % dwpr) * 4;
-    uint32_t w = 0;
-    const int sy = y - pad_y;
+    const uint8_t *src = p.src[blockIdx.y];
+    uint8_t *dst = p.dst[blockIdx.y];
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;    // 16 output bytes (pw is a multiple of 4)
+    const int per_row = (pw + 15) / 16;
+    if (t >= (long long)per_row * ph) return;
+    const int y = (int)(t / per_row), x0 = (int)(t % per_row) * 16;
+    const int sy = y - pad_y, sx0 = x0 - pad_x;
+    uint32_t w[4] = {0, 0, 0, 0};
     if (sy >= 0 && sy < height) {
+        const uint8_t *row = src + (size_t)sy * pitch;
+        if (sx0 >= 0 && sx0 + 16 <= width) {                           // inside: one (unaligned) 16-byte load
+            const ua_u128 v = *reinterpret_cast<const ua_u128 *>(row + sx0);
+            w[0] = v.v[0]; w[1] = v.v[1]; w[2] = v.v[2]; w[3] = v.v[3];
+        } else {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int sx = x0 + b - pad_x;
-            if (sx >= 0 && sx < width) w |= (uint32_t)src[(size_t)sy * pitch + sx] << (8 * b);
+            for (int b = 0; b < 16; ++b) {
+                const int sx = sx0 + b;
+                if (sx >= 0 && sx < width) w[b >> 2] |= (uint32_t)row[sx] << (8 * (b & 3));
+            }
         }
     }
-    *reinterpret_cast<uint32_t *>(dst + (size_t)y * pw + x0) = w;
+    uint32_t *out = reinterpret_cast<uint32_t *>(dst + (size_t)y * pw + x0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (x0 + 4 * q < pw) out[q] = w[q];
 }
 
 __device__ __forceinline__ int mirror101(int p, int n)
@@ -1224,8 +1275,11 @@ __device__ __forceinline__ int mirror101(int p, int n)
     return p;
 }
 
-__global__ __launch_bounds__(256) void k_pyr_down(const uint8_t *src, int sw, int sh, uint8_t *dst)
+// one output pixel per thread: planes whose half width is not a multiple of 4
+__global__ __launch_bounds__(256) void k_pyr_down(PlanePair p, int sw, int sh)
 {
+    const uint8_t *src = p.src[blockIdx.y];
+    uint8_t *dst = p.dst[blockIdx.y];
     const int dw = sw / 2, dh = sh / 2;
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= (long long)dw * dh) return;
@@ -1244,6 +1298,46 @@ __global__ __launch_bounds__(256) void k_pyr_down(const uint8_t *src, int sw, in
         acc += wgt[ky] * h;
     }
     dst[(size_t)y * dw + x] = (uint8_t)((acc + 128) >> 8);
+}
+
+// four output pixels per thread (sw a multiple of 8): output x = 4k + c reads input bytes 8k + 2c - 2 .. 8k + 2c + 2, all
+// inside the four dwords at 8k - 4 .. 8k + 11.  h = [1 4 6 4] . bytes[o .. o+3] (v_dot4_u32_u8 on a re-aligned dword)
+// + byte[o + 4]; out = (h0 + 4 h1 + 6 h2 + 4 h3 + h4 + 128) >> 8 over the five (mirrored) rows -- the same integers as
+// the separable host form, no rounding in between.
+__global__ __launch_bounds__(256) void k_pyr_down4(PlanePair p, int sw, int sh)
+{
+    const uint8_t *src = p.src[blockIdx.y];
+    uint8_t *dst = p.dst[blockIdx.y];
+    const int dw = sw / 2, dh = sh / 2, per_row = dw / 4;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)per_row * dh) return;
+    const int k = (int)(t % per_row), y = (int)(t / per_row);
+    const bool left = k == 0, right = 8 * k + 12 > sw;                // sw % 8 == 0: the last thread of a row
+    const uint32_t taps = 1u | 4u << 8 | 6u << 16 | 4u << 24;
+    uint32_t acc[4] = {128, 128, 128, 128};
+    const uint32_t wy[5] = {1, 4, 6, 4, 1};
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(src + (size_t)mirror101(2 * y + ky - 2, sh) * sw + 8 * k);
+        uint32_t d[4];
+        d[1] = row[0]; d[2] = row[1];                                   // input bytes 8k .. 8k+7: always inside the row
+        d[0] = left ? 0u : row[-1];
+        d[3] = right ? 0u : row[2];
+        // BORDER_REFLECT_101 at the row ends, without divergent byte loops: of d[0] only input bytes -2, -1 (= 2, 1) are
+        // used, of d[3] only input byte 8k+8 (= sw, mirrored to sw - 2 = 8k+6)
+        if (left) d[0] = (d[1] & 0x00ff0000u) | (d[1] & 0x0000ff00u) << 16;
+        if (right) d[3] = (d[2] >> 16) & 0xffu;
+        // byte offsets inside d[]: window of output c starts at 2c + 2
+        const uint32_t w0 = __builtin_amdgcn_alignbyte(d[1], d[0], 2), w1 = d[1];
+        const uint32_t w2 = __builtin_amdgcn_alignbyte(d[2], d[1], 2), w3 = d[2];
+        const uint32_t h0 = __builtin_amdgcn_udot4(w0, taps, (d[1] >> 16) & 0xffu, false);
+        const uint32_t h1 = __builtin_amdgcn_udot4(w1, taps, d[2] & 0xffu, false);
+        const uint32_t h2 = __builtin_amdgcn_udot4(w2, taps, (d[2] >> 16) & 0xffu, false);
+        const uint32_t h3 = __builtin_amdgcn_udot4(w3, taps, d[3] & 0xffu, false);
+        acc[0] += wy[ky] * h0; acc[1] += wy[ky] * h1; acc[2] += wy[ky] * h2; acc[3] += wy[ky] * h3;
+    }
+    const uint32_t out = (acc[0] >> 8) | (acc[1] >> 8) << 8 | (acc[2] >> 8) << 16 | (acc[3] >> 8) << 24;
+    *reinterpret_cast<uint32_t *>(dst + (size_t)y * dw + 4 * k) = out;
 }
 
 // =======================================================================================

@@ -91,6 +91,10 @@ class MF:
         _capi.check(self._lib.bbme_set_frames_device(self._ctx, image1.data_ptr(), image2.data_ptr(),
                                                      image1.stride(0)))
 
+    def set_search_mode(self, raster):
+        """False: find_min_block_spiral (the reference's live search); True: the raster find_min_block (:246-294)."""
+        _capi.check(self._lib.bbme_set_search_mode(self._ctx, 1 if raster else 0))
+
     def set_speculation(self, enabled):
         """Speculative search of the next finer level beside a level's late sweeps (bbme_set_speculation); same result."""
         _capi.check(self._lib.bbme_set_speculation(self._ctx, int(bool(enabled))))

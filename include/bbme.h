@@ -115,6 +115,8 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
 int bbme_destroy(bbme_ctx *ctx);
 /* hipStream_t to run on (default: a stream the ctx creates).  Pass the raw handle. */
 int bbme_set_stream(bbme_ctx *ctx, void *hip_stream);
+/* The raw hipStream_t the context enqueues on (to order other work, e.g. a collective, behind bbme_estimate). */
+int bbme_get_stream(bbme_ctx *ctx, void **hip_stream);
 int bbme_get_geometry(const bbme_ctx *ctx, int *padded_width, int *padded_height,
                       int *pad_x, int *pad_y);
 int bbme_level_geometry(const bbme_ctx *ctx, int level, int *width, int *height,
@@ -128,6 +130,13 @@ int bbme_set_frames_host(bbme_ctx *ctx, const uint8_t *image1, const uint8_t *im
 /* Same constructor for frames already resident in HBM (unpadded, width x height):
  * zero padding and the whole pyrDown cascade run as HIP kernels on the ctx stream. */
 int bbme_set_frames_device(bbme_ctx *ctx, const uint8_t *d_image1, const uint8_t *d_image2, int pitch);
+/* Which of the reference's two block searches MF::calcLevelBM calls (motion_framework.cpp:235-236): the spiral full
+ * search find_min_block_spiral (:296-422, the live one: ties go to the candidate visited first on the spiral; a
+ * prediction outside the image gives a zero MV) or the raster full search find_min_block (:246-294, commented out in the
+ * reference: window clamped to the image, ties go to the candidate closer (L1) to the block's own position, then to the
+ * first in raster order; a window entirely outside the image leaves the prediction as the result).  Default: spiral. */
+enum { BBME_SEARCH_SPIRAL = 0, BBME_SEARCH_RASTER = 1 };
+int bbme_set_search_mode(bbme_ctx *ctx, int mode);
 /* Scheduling option (default on; BBME_SPECULATE=0 turns the default off): bbme_estimate starts the search of every level
  * but the coarsest on a second stream beside the coarser level's late regulariser sweeps, predicting from that level's grid
  * as it stands, and afterwards searches again the blocks whose prediction those sweeps changed.  Same field, bit for bit;

@@ -13,6 +13,7 @@
 #include "bbme_oracle.h"
 
 #include <float.h>
+#include <limits.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -373,6 +374,42 @@ void orc_find_min_block_spiral(orc_mf *mf, int level, int image1_ypos, int image
     *pos_x = s.min_x; *pos_y = s.min_y;
 }
 
+/* ------------------------------------------------------------------------ */
+/* MF::find_min_block :246-294 -- the raster full search whose call is commented */
+/* out at :235.  Window clamped to the image (:260,262), no special case for a   */
+/* prediction outside it; among equal SADs the block closer (L1) to the block's  */
+/* own position wins (:276-281), the first one in raster order among those.       */
+/* ------------------------------------------------------------------------ */
+static int imin(int a, int b) { return a < b ? a : b; }
+static int imax(int a, int b) { return a > b ? a : b; }
+
+void orc_find_min_block(orc_mf *mf, int level, int image1_ypos, int image1_xpos,
+                        int image2_ypos, int image2_xpos, int *pos_x, int *pos_y)
+{
+    orc_level *lv = &mf->lv[level];
+    int start_pos = (lv->search_size - lv->block_size) >> 1;          /* :249 */
+    int SAD_min = INT_MAX;                                             /* :250 */
+    int min_x = image2_xpos, min_y = image2_ypos;                      /* :251-252 */
+    int l1_dist = INT_MAX;                                             /* :257 */
+    int bs = lv->block_size, width = lv->width, height = lv->height;
+    for (int k = imax(0, image2_ypos - start_pos); k < imin(height - bs + 1, image2_ypos + start_pos + 1); k++)      /* :260 */
+        for (int l = imax(0, image2_xpos - start_pos); l < imin(width - bs + 1, image2_xpos + start_pos + 1); l++) { /* :262 */
+            int sad = l1_norm_u8(lv->image1 + (size_t)image1_ypos * width + image1_xpos, width,
+                                 lv->image2 + (size_t)k * width + l, width, bs);                                      /* :265 */
+            int d = abs(image1_xpos - l) + abs(image1_ypos - k);
+            if (sad < SAD_min) {                                       /* :269-275 */
+                SAD_min = sad; min_x = l; min_y = k; l1_dist = d;
+            } else if (sad == SAD_min && d < l1_dist) {                /* :276-281 */
+                min_x = l; min_y = k; l1_dist = d;
+            }
+        }
+    if (lv->cache) {                                                   /* :286 */
+        int32_t *c = CACHE_AT(lv, image1_ypos, image1_xpos);
+        c[0] = min_x; c[1] = min_y; c[2] = SAD_min; c[3] = bs;
+    }
+    *pos_x = min_x; *pos_y = min_y;
+}
+
 int orc_spiral_walk(int shift, int *dx, int *dy, int cap)
 {
     int n = 0, l = 0, k = 0, m, t;
@@ -406,7 +443,8 @@ void orc_calc_level_bm(orc_mf *mf, int level)
             int x2 = j + (int)f[0];                                   /* :233 */
             int y2 = i + (int)f[1];                                   /* :234 */
             int rx, ry;
-            orc_find_min_block_spiral(mf, level, i, j, y2, x2, &rx, &ry);   /* :236 */
+            if (mf->raster_search) orc_find_min_block(mf, level, i, j, y2, x2, &rx, &ry);   /* :235 */
+            else orc_find_min_block_spiral(mf, level, i, j, y2, x2, &rx, &ry);              /* :236 */
             f[0] = (float)rx - j;                                     /* :238-239 */
             f[1] = (float)ry - i;
         }

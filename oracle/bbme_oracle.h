@@ -51,6 +51,8 @@ typedef struct {
     int padded_height, padded_width, padding_x, padding_y; /* public MF fields   */
     int orig_height, orig_width;
     int use_cache;
+    int raster_search;     /* 1: calcLevelBM calls find_min_block (:235, commented out in the reference) instead of
+                              find_min_block_spiral (:236) */
 } orc_mf;
 
 /* ---- MF constructor pieces (motion_framework.cpp:4-111) ---- */

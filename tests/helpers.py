@@ -49,12 +49,15 @@ def gpu_schedule(mf, levels, blocks, on_stage=None):
     return mf.get_flow()
 
 
-def compare_stagewise(bbme, oracle, f1, f2, search, block, use_planes=True):
+def compare_stagewise(bbme, oracle, f1, f2, search, block, use_planes=True, raster=False):
     """Runs both sides stage by stage on the same planes; asserts every grid is identical.
     Returns (flow_gpu, flow_oracle)."""
     L = len(block)
     omf = oracle.OracleMF(f1, f2, search, block)
     mf = bbme.MF(f1, f2, search, block, L)
+    if raster:
+        omf.set_raster_search(True)
+        mf.set_search_mode(True)
     assert (mf.padded_width, mf.padded_height, mf.padding_x, mf.padding_y) == \
            (omf.padded_width, omf.padded_height, omf.padding_x, omf.padding_y)
     if use_planes:

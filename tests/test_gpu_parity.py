@@ -295,6 +295,38 @@ def test_device_frames_gpu_pyramid(bbme, oracle):
     mf.close()
 
 
+@pytest.mark.parametrize("w,h,search,block", [
+    (250, 130, [30], [16]),                              # padded both ways, one level (border copy only)
+    (100, 60, [12, 12, 12], [4, 4, 4]),                  # level widths 104 / 52 / 26: the one-pixel-per-thread pyrDown
+    (1000, 700, [24, 24, 24, 24], [8, 8, 8, 8]),         # odd-looking size, four levels
+    (1920, 1080, [48, 48, 48], [16, 16, 16]),            # cfg2
+    (3840, 2160, [80, 80, 80, 80], [16, 16, 16, 16]),    # cfg3: the bench's geometry
+])
+def test_gpu_pyramid_planes_match_the_oracle(bbme, oracle, w, h, search, block):
+    """MF::MF on the GPU (zero border :57-61, pyrDown cascade :86-106) for frames in HBM and for host frames (which take
+    the same kernels): every plane of every level equals the oracle's, including rows of a strided (pitch > width) tensor."""
+    import torch
+    rng = np.random.default_rng(w * 7 + h)
+    f1 = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    f2 = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    L = len(block)
+    omf = oracle.OracleMF(f1, f2, search, block)
+    wide = torch.zeros((2, h, w + 13), dtype=torch.uint8, device="cuda")
+    wide[0, :, :w] = torch.from_numpy(f1).cuda()
+    wide[1, :, :w] = torch.from_numpy(f2).cuda()
+    for frames_on_device in (True, False):
+        if frames_on_device:
+            mf = bbme.MF(wide[0, :, :w], wide[1, :, :w], search, block, L, frames_on_device=True)
+        else:
+            mf = bbme.MF(f1, f2, search, block, L)
+        for lvl in range(L):
+            a, b = mf.get_level_planes(lvl)
+            assert np.array_equal(a, omf.image(lvl, 1)), "image1 plane of level %d (device frames: %s)" % (lvl, frames_on_device)
+            assert np.array_equal(b, omf.image(lvl, 2)), "image2 plane of level %d (device frames: %s)" % (lvl, frames_on_device)
+        mf.close()
+    omf.close()
+
+
 def _write_pgm(path, img):
     with open(path, "wb") as f:
         f.write(b"P5\n# bbme test frame\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
@@ -517,3 +549,78 @@ def test_cell_gather_world_size_one_nccl(bbme, oracle):
     finally:
         dist.destroy_process_group()
         omf.close()
+
+
+RASTER_CASES = [
+    (320, 208, [30, 30, 30], [16, 16, 16], 2001, 12),           # B=16, R=7, 3 levels
+    (384, 256, [48, 48], [16, 16], 2002, 24),                   # R=16
+    (256, 256, [72, 72], [8, 8], 2003, 20),                     # B=8, R=32: windows and predictions leave the image
+    (512, 512, [64, 64, 64], [32, 32, 32], 2004, 30),           # the reference's literals
+    (256, 192, [12, 12], [4, 4], 2005, 5),                      # B=4
+    (256, 128, [17, 21], [16, 16], 2006, 3),                    # odd search - block
+]
+
+
+@pytest.mark.parametrize("w,h,search,block,seed,mm", RASTER_CASES)
+def test_raster_search_variant_stagewise(bbme, oracle, w, h, search, block, seed, mm):
+    """SURVEY 8(f4): MF::find_min_block (motion_framework.cpp:246-294, the raster search whose call is commented out at
+    :235) as the level's search -- clamped window, ties to the candidate nearest the block's own position, then raster
+    order -- every stage against the oracle's restatement of it."""
+    f1, f2, _ = bbme.synth_pair(w, h, seed, max_motion=mm)
+    compare_stagewise(bbme, oracle, f1, f2, search, block, raster=True)
+
+
+def test_raster_search_ties_and_outside_predictions(bbme, oracle):
+    """Raster mode where its rules differ from the spiral's: flat frames (every SAD equal: the winner is the candidate
+    nearest the zero-MV position), periodic texture, and coarse motion that throws predictions outside the image (the
+    window is clamped; an empty window leaves the prediction as the result)."""
+    z = np.full((128, 192), 90, np.uint8)
+    compare_stagewise(bbme, oracle, z, z, [48, 48], [16, 16], raster=True)
+    y, x = np.mgrid[0:192, 0:256]
+    stripes = ((x // 4) % 2 * 200).astype(np.uint8)
+    compare_stagewise(bbme, oracle, stripes, np.roll(stripes, 3, axis=1), [48, 48], [16, 16], raster=True)
+    rng = np.random.default_rng(17)
+    f1 = rng.integers(0, 256, (256, 320), dtype=np.uint8)
+    f2 = np.roll(f1, (37, -45), axis=(0, 1))
+    compare_stagewise(bbme, oracle, f1, f2, [80, 80, 80], [16, 16, 16], raster=True)
+    # full pipeline through the graph (speculative search + fix-up) in raster mode
+    omf = oracle.OracleMF(f1, f2, [80, 80, 80], [16, 16, 16])
+    omf.set_raster_search(True)
+    exp = omf.calc_motion_block_matching()
+    mf = bbme.MF(f1, f2, [80, 80, 80], [16, 16, 16], 3)
+    mf.set_search_mode(True)
+    for lvl in range(3):
+        mf.set_level_planes(lvl, omf.image(lvl, 1), omf.image(lvl, 2))
+    assert np.array_equal(mf.calcMotionBlockMatching(), exp)
+    mf.set_search_mode(False)                                   # and back: the spiral result differs and is the plain oracle's
+    omf.close()
+    omf = oracle.OracleMF(f1, f2, [80, 80, 80], [16, 16, 16])
+    assert np.array_equal(mf.calcMotionBlockMatching(), omf.calc_motion_block_matching())
+    mf.close(); omf.close()
+
+
+def test_cpp_sequence_driver_over_rccl(bbme, oracle, tmp_path):
+    """bbme_seq: the multi-GPU sequence without torch -- contexts per GPU, ncclGather of the cell grids through
+    libbbme_rccl.so (bbme_gather_cells), expansion on the root, asynchronous .flo writer -- here with the one GPU of this
+    box (an RCCL communicator of size one, three pairs = three rounds): every file equals the oracle's field."""
+    import subprocess
+    from blockbasedmotionestimation_amd import build as _build
+    search, block = 40, 8
+    files, expect = [], []
+    for p in range(3):
+        f1, f2, _ = bbme.synth_pair(328, 200, 8800 + p, max_motion=10)
+        for tag, img in (("a", f1), ("b", f2)):
+            path = str(tmp_path / ("%d%s.pgm" % (p, tag)))
+            _write_pgm(path, img)
+            files.append(path)
+        omf = oracle.OracleMF(f1, f2, [search] * 3, [block] * 3)
+        full = omf.calc_motion_block_matching()
+        expect.append(full[omf.padding_y:omf.padding_y + 200, omf.padding_x:omf.padding_x + 328])
+        omf.close()
+    r = subprocess.run([_build.SEQ, "--gpus", "1", "--levels", "3", "--block", str(block), "--search", str(search),
+                        "--out", str(tmp_path)] + files, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "3 pairs of 328x200 on 1 GPU(s)" in r.stdout
+    for p in range(3):
+        got = bbme.Flow().ReadFlowFile(str(tmp_path / ("%04d.flo" % p)))
+        assert np.array_equal(got, expect[p]), "pair %d" % p

@@ -24,6 +24,21 @@ def test_library_exports_every_declared_symbol(bbme):
     assert _capi.lib().bbme_version().startswith(b"bbme")
 
 
+def test_rccl_library_exports_its_header(bbme):
+    """libbbme_rccl.so (the multi-GPU gather without torch) exports what include/bbme_rccl.h declares, and the sequence
+    driver built on it exists and explains itself."""
+    import subprocess
+    from blockbasedmotionestimation_amd import build as _build
+    header = open(os.path.join(ROOT, "include", "bbme_rccl.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(bbme_[a-z0-9_]+)\s*\(", header))
+    assert declared == {"bbme_gather_cells", "bbme_expand_gathered"}
+    lib = C.CDLL(_build.RCCL_LIB)
+    assert all(hasattr(lib, s) for s in declared)
+    r = subprocess.run([_build.SEQ], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage: bbme_seq" in r.stderr
+
+
 def test_no_cpu_fallback_without_device(bbme):
     """The product fails loudly when no GPU can be used: there is no CPU compute path."""
     if os.path.exists("/dev/kfd"):

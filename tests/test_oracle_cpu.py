@@ -244,3 +244,37 @@ def test_flo_read_rejects_what_the_reference_rejects(oracle, tmp_path):
         oracle.flo_read(str(p))
     with pytest.raises(IOError):
         oracle.flo_read(str(tmp_path / "missing.flo"))
+
+
+def test_raster_find_min_block_against_numpy_brute_force(oracle):
+    """The oracle's MF::find_min_block (motion_framework.cpp:246-294, SURVEY 8f4) against a direct numpy statement of its
+    rules: window clamped to the image, lowest SAD, then the smaller L1 distance to the block's own position, then the
+    first in raster order.  Two levels, so that level 0 starts from non-zero (and partly outside) predictions."""
+    from blockbasedmotionestimation_amd.synth import synth_pair
+    f1, f2, _ = synth_pair(160, 96, 5, max_motion=14)
+    B, R = 8, 6
+    omf = oracle.OracleMF(f1, f2, [B + 2 * R] * 2, [B] * 2)
+    omf.set_raster_search(True)
+    omf.calc_level_bm(1)
+    for lvl in (1, 0):
+        if lvl == 0:
+            omf.copy_mvs(0)
+            pred = omf.block_mvs(0, B).copy()
+            omf.calc_level_bm(0)
+        else:
+            pred = np.zeros(omf.block_mvs(1, B).shape, np.int32)
+        got = omf.block_mvs(lvl, B)
+        i1, i2 = omf.image(lvl, 1).astype(int), omf.image(lvl, 2).astype(int)
+        H, W = i1.shape
+        for i in range(0, H, B):
+            for j in range(0, W, B):
+                px, py = j + int(pred[i // B, j // B, 0]), i + int(pred[i // B, j // B, 1])
+                best = (None, None, px, py)
+                for k in range(max(0, py - R), min(H - B + 1, py + R + 1)):
+                    for l in range(max(0, px - R), min(W - B + 1, px + R + 1)):
+                        sad = int(np.abs(i1[i:i + B, j:j + B] - i2[k:k + B, l:l + B]).sum())
+                        d = abs(j - l) + abs(i - k)
+                        if best[0] is None or sad < best[0] or (sad == best[0] and d < best[1]):
+                            best = (sad, d, l, k)
+                assert list(got[i // B, j // B]) == [best[2] - j, best[3] - i], (lvl, i, j)
+    omf.close()
