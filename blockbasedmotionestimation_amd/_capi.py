@@ -96,6 +96,7 @@ SIGNATURES = {
     "bbme_probe_latency": (C.c_int, [C.c_int, _P(C.c_ulonglong)]),
     "bbme_probe_xcd": (C.c_int, [C.c_int, _P(C.c_int), _P(C.c_int)]),
     "bbme_set_search_mode": (C.c_int, [_ctx, C.c_int]),
+    "bbme_set_regularizer_mode": (C.c_int, [_ctx, C.c_int]),
     "bbme_set_speculation": (C.c_int, [_ctx, C.c_int]),
     "bbme_wait_for_stream": (C.c_int, [_ctx, C.c_void_p]),
     "bbme_calibrate_read": (C.c_int, [C.c_int, C.c_uint, C.c_int]),

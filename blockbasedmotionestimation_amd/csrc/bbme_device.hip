@@ -73,6 +73,7 @@ struct bbme_ctx {
     int solve_waves = 4;                          // waves per solver workgroup (1, 2 or 4); BBME_SOLVE_WAVES
     int solve_wgs = 256;                          // most workgroups of k_reg_solve (4 independent waves each): one wave per SIMD
     int xcd_remap = 1;                            // XCD-aware block order in k_search_fast; BBME_XCD_REMAP
+    bool jacobi = false;                          // opt-in, not bit-exact: Jacobi sweeps (pass 1 only); bbme_set_regularizer_mode
     bool raster_search = false;                   // MF::find_min_block (:246-294) instead of the spiral search; bbme_set_search_mode
     bool force_generic_search = false;            // BBME_GENERIC_SEARCH=1: use k_search_generic everywhere
     bool use_graph = true;
@@ -227,7 +228,8 @@ int launch_search(bbme_ctx *c, int level, int mode = kSearchPlain, hipStream_t s
 }
 
 template <int BS>
-void launch_sweep_t(RegArgs a, uint8_t *const flags[2], int relax_steps, int max_solve_wgs, int solve_waves, hipStream_t s)
+void launch_sweep_t(RegArgs a, uint8_t *const flags[2], int relax_steps, int max_solve_wgs, int solve_waves, bool jacobi,
+                    hipStream_t s)
 {
     constexpr int LPB = RegCfg<BS>::LPB;
     const long long blocks = (long long)a.rows * a.cols;
@@ -236,6 +238,12 @@ void launch_sweep_t(RegArgs a, uint8_t *const flags[2], int relax_steps, int max
     const int grid2 = (int)((std::min<long long>(max_solve_wgs, (blocks + 63) / 64) + 7) / 8 * 8);
     // pass 1 marks flags[0]; relaxation step i consumes flags[i & 1] and marks the other; the solver
     // consumes what the last step marked.  Every flag is zero again afterwards.
+    if (jacobi) {
+        // opt-in, NOT the reference's field: every block against the field as the previous sweep left it, and no more
+        a.flag_cur = nullptr; a.flag_next = nullptr;
+        hipLaunchKernelGGL(k_reg_pass1<BS>, dim3(grid1), dim3(256), 0, s, a);
+        return;
+    }
     a.flag_cur = nullptr; a.flag_next = flags[0];
     hipLaunchKernelGGL(k_reg_pass1<BS>, dim3(grid1), dim3(256), 0, s, a);
     int cur = 0;
@@ -301,12 +309,12 @@ int launch_sweep(bbme_ctx *c, int level, int b, int mult)
         steps = (nblk >= min_blocks && b <= max_b) ? (mult == 1 ? s1 : s2) : 0;
     }
     switch (b) {
-    case 2:  launch_sweep_t<2>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->stream); break;
-    case 4:  launch_sweep_t<4>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->stream); break;
-    case 8:  launch_sweep_t<8>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->stream); break;
-    case 16: launch_sweep_t<16>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->stream); break;
-    case 32: launch_sweep_t<32>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->stream); break;
-    case 64: launch_sweep_t<64>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->stream); break;
+    case 2:  launch_sweep_t<2>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->stream); break;
+    case 4:  launch_sweep_t<4>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->stream); break;
+    case 8:  launch_sweep_t<8>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->stream); break;
+    case 16: launch_sweep_t<16>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->stream); break;
+    case 32: launch_sweep_t<32>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->stream); break;
+    case 64: launch_sweep_t<64>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->stream); break;
     default: return bbme::fail(BBME_ERR_UNSUPPORTED, "block size %d", b);
     }
     HIP_TRY(hipGetLastError());
@@ -334,6 +342,8 @@ int launch_expand(bbme_ctx *c)
 int enqueue_pyramid(bbme_ctx *c, bool speculate)
 {
     const int nl = (int)c->lv.size();
+    if (speculate && nl > 1 && !c->side_stream)         // only contexts that speculate hold a second stream (hardware queue)
+        HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
     bool speculated = false;
     for (int l = nl - 1; l >= 0; --l) {
         if (speculated) {
@@ -449,8 +459,7 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
     hipError_t err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (err != hipSuccess) return cleanup_fail(bbme::fail(BBME_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(err)));
     c->own_stream = true;
-    if ((err = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking)) != hipSuccess ||
-        (err = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess ||
+    if ((err = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess ||
         (err = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess)
         return cleanup_fail(bbme::fail(BBME_ERR_HIP, "creating the side stream: %s", hipGetErrorString(err)));
     size_t max_blocks = 0;
@@ -575,6 +584,18 @@ int bbme_set_search_mode(bbme_ctx *c, int mode)
     return BBME_OK;
 }
 
+int bbme_set_regularizer_mode(bbme_ctx *c, int mode)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (mode != BBME_REG_EXACT && mode != BBME_REG_JACOBI) return bbme::fail(BBME_ERR_INVALID, "regulariser mode %d", mode);
+    if (c->jacobi == (mode == BBME_REG_JACOBI)) return BBME_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    drop_graph(c);
+    c->jacobi = mode == BBME_REG_JACOBI;
+    return BBME_OK;
+}
+
 int bbme_set_speculation(bbme_ctx *c, int enabled)
 {
     if (int rc = check_ctx(c)) return rc;
@@ -583,6 +604,7 @@ int bbme_set_speculation(bbme_ctx *c, int enabled)
     HIP_TRY(hipStreamSynchronize(c->stream));
     drop_graph(c);                                   // the launch sequence changes
     c->speculate = enabled != 0;
+    if (!c->speculate && c->side_stream) { (void)hipStreamDestroy(c->side_stream); c->side_stream = nullptr; }
     return BBME_OK;
 }
 

@@ -814,7 +814,7 @@ __global__ __launch_bounds__(256) void k_reg_pass1(RegArgs a)
         a.est[g] = res;
         // the blocks that read this one as an already-updated input assumed the old value
         const mv_t old = a.old_grid[(size_t)(r >> a.old_shift) * a.old_cols + (c >> a.old_shift)];
-        if (res != old) mark_dependants(a, a.flag_next, r, c);
+        if (a.flag_next && res != old) mark_dependants(a, a.flag_next, r, c);     // no map: the Jacobi fast mode stops here
     }
 }
 

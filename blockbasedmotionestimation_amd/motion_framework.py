@@ -95,6 +95,10 @@ class MF:
         """False: find_min_block_spiral (the reference's live search); True: the raster find_min_block (:246-294)."""
         _capi.check(self._lib.bbme_set_search_mode(self._ctx, 1 if raster else 0))
 
+    def set_regularizer_mode(self, jacobi):
+        """False: the reference's in-place raster sweep, bit for bit.  True: opt-in Jacobi sweeps (not the reference's field)."""
+        _capi.check(self._lib.bbme_set_regularizer_mode(self._ctx, 1 if jacobi else 0))
+
     def set_speculation(self, enabled):
         """Speculative search of the next finer level beside a level's late sweeps (bbme_set_speculation); same result."""
         _capi.check(self._lib.bbme_set_speculation(self._ctx, int(bool(enabled))))

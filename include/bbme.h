@@ -137,6 +137,14 @@ int bbme_set_frames_device(bbme_ctx *ctx, const uint8_t *d_image1, const uint8_t
  * first in raster order; a window entirely outside the image leaves the prediction as the result).  Default: spiral. */
 enum { BBME_SEARCH_SPIRAL = 0, BBME_SEARCH_RASTER = 1 };
 int bbme_set_search_mode(bbme_ctx *ctx, int mode);
+/* BBME_REG_EXACT (default): every sweep leaves exactly the field of the reference's in-place raster sweep
+ * (regularize_MVs writes each winner straight back, :616, and later blocks of the same sweep read it, :441-449).
+ * BBME_REG_JACOBI: opt-in fast mode, NOT the reference's result -- every block of a sweep is evaluated against the field
+ * as the previous sweep left it (one fully parallel pass per sweep, no dependent chains).  Same candidates, energies and
+ * tie rules per block; the fields differ where a sweep's changes would have propagated within the sweep.  bench.py
+ * reports its speed and its end-point error beside the exact mode's, never as `value`. */
+enum { BBME_REG_EXACT = 0, BBME_REG_JACOBI = 1 };
+int bbme_set_regularizer_mode(bbme_ctx *ctx, int mode);
 /* Scheduling option (default on; BBME_SPECULATE=0 turns the default off): bbme_estimate starts the search of every level
  * but the coarsest on a second stream beside the coarser level's late regulariser sweeps, predicting from that level's grid
  * as it stands, and afterwards searches again the blocks whose prediction those sweeps changed.  Same field, bit for bit;

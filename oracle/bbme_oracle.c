@@ -541,6 +541,19 @@ void orc_regularize_mvs(orc_mf *mf, int level)
         abort();
     }
     float cand[9][2];
+    /* jacobi_regularizer (not the reference; the checker of the product's opt-in fast mode): candidates come from a
+     * snapshot of the field taken before the sweep instead of the field being rewritten (:616) */
+    int cols = width / bs;
+    float *snap = NULL;
+    if (mf->jacobi_regularizer) {
+        snap = (float *)malloc(sizeof(float) * 2 * (size_t)cols * (height / bs));
+        for (int i = 0; i < height; i += bs)
+            for (int j = 0; j < width; j += bs) {
+                const float *f = FLOW_AT(lv, i, j);
+                snap[2 * ((size_t)(i / bs) * cols + j / bs)] = f[0];
+                snap[2 * ((size_t)(i / bs) * cols + j / bs) + 1] = f[1];
+            }
+    }
     for (int i = 0; i < height; i += bs)
         for (int j = 0; j < width; j += bs) {
             const nb_case *c;
@@ -554,11 +567,13 @@ void orc_regularize_mvs(orc_mf *mf, int level)
             else if (j == 0)                                                     c = &NB_BL;       /* :508 */
             else                                                                 c = &NB_BR;       /* :516 */
             for (int k = 0; k < c->n; ++k) {
-                const float *f = FLOW_AT(lv, i + c->off[k][0] * bs, j + c->off[k][1] * bs);
+                const float *f = snap ? snap + 2 * ((size_t)(i / bs + c->off[k][0]) * cols + j / bs + c->off[k][1])
+                                      : FLOW_AT(lv, i + c->off[k][0] * bs, j + c->off[k][1] * bs);
                 cand[k][0] = f[0]; cand[k][1] = f[1];
             }
             find_min_candidate(mf, lv, j, i, (const float (*)[2])cand, c->n);   /* :524 */
         }
+    free(snap);
 }
 
 /* ------------------------------------------------------------------------ */

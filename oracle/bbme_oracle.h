@@ -53,6 +53,8 @@ typedef struct {
     int use_cache;
     int raster_search;     /* 1: calcLevelBM calls find_min_block (:235, commented out in the reference) instead of
                               find_min_block_spiral (:236) */
+    int jacobi_regularizer; /* 1: NOT the reference -- every sweep reads only the field as the previous sweep left it (the
+                               product's opt-in fast mode); 0: the reference's in-place raster sweep */
 } orc_mf;
 
 /* ---- MF constructor pieces (motion_framework.cpp:4-111) ---- */

@@ -29,7 +29,7 @@ class _MF(C.Structure):
                 ("padded_height", C.c_int), ("padded_width", C.c_int),
                 ("padding_x", C.c_int), ("padding_y", C.c_int),
                 ("orig_height", C.c_int), ("orig_width", C.c_int), ("use_cache", C.c_int),
-                ("raster_search", C.c_int)]
+                ("raster_search", C.c_int), ("jacobi_regularizer", C.c_int)]
 
 
 def build(force=False):
@@ -157,6 +157,10 @@ class OracleMF:
         m = self._p.contents
         self.padded_height, self.padded_width = m.padded_height, m.padded_width
         self.padding_x, self.padding_y = m.padding_x, m.padding_y
+
+    def set_jacobi_regularizer(self, flag):
+        """NOT the reference: sweeps read the field as the previous sweep left it (checker of the product's fast mode)."""
+        self._p.contents.jacobi_regularizer = int(bool(flag))
 
     def set_raster_search(self, flag):
         """calcLevelBM calls find_min_block (:235) instead of find_min_block_spiral (:236)."""

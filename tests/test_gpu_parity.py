@@ -624,3 +624,29 @@ def test_cpp_sequence_driver_over_rccl(bbme, oracle, tmp_path):
     for p in range(3):
         got = bbme.Flow().ReadFlowFile(str(tmp_path / ("%04d.flo" % p)))
         assert np.array_equal(got, expect[p]), "pair %d" % p
+
+
+def test_jacobi_fast_mode_is_what_it_says(bbme, oracle):
+    """the opt-in, NOT bit-exact regulariser mode.  Its definition -- every block of a sweep evaluated
+    against the field as the previous sweep left it -- is restated in the oracle (jacobi_regularizer), and the kernels
+    must produce exactly that field; it must differ from the reference's field on content where sweeps propagate, and
+    switching back must give the reference's field again."""
+    f1, f2, _ = bbme.synth_pair(512, 384, 3100, max_motion=20)
+    search, block = [48, 48, 48], [16, 16, 16]
+    omf = oracle.OracleMF(f1, f2, search, block)
+    exact = omf.calc_motion_block_matching().copy()
+    omf.close()
+    omf = oracle.OracleMF(f1, f2, search, block)
+    omf.set_jacobi_regularizer(True)
+    jac = omf.calc_motion_block_matching().copy()
+    mf = bbme.MF(f1, f2, search, block, 3)
+    for lvl in range(3):
+        mf.set_level_planes(lvl, omf.image(lvl, 1), omf.image(lvl, 2))
+    omf.close()
+    mf.set_regularizer_mode(True)
+    got = mf.calcMotionBlockMatching()
+    assert np.array_equal(got, jac)
+    assert not np.array_equal(jac, exact)
+    mf.set_regularizer_mode(False)
+    assert np.array_equal(mf.calcMotionBlockMatching(), exact)
+    mf.close()
