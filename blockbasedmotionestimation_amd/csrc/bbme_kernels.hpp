@@ -338,7 +338,7 @@ template <int B>
 __device__ __forceinline__ void search_block_fast(const FastSearchArgs &a, uint32_t bid, mv_t m, uint32_t *smem)
 {
     constexpr int BW = B / 4;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int bc = (int)(bid % (uint32_t)a.cols), br = (int)(bid / (uint32_t)a.cols);
     const int i = br * B, j = bc * B;
     const int u = 2 * mv_x(m), v = 2 * mv_y(m);             // copyMVs doubles the coarse MV (:836)
