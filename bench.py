@@ -114,8 +114,10 @@ def cpu_baseline(f1, f2, search, block, levels, expect_flow):
     src = os.path.join(ROOT, "oracle", "bbme_oracle.c")
     tmp = tempfile.mkdtemp(prefix="bbme_cpu_")
     _, _, usable = cpu_info()
+    # a 1-GPU box gives this job a share of 16 host cores whatever nproc says; BBME_CPU_THREADS overrides
+    pool = max(1, min(usable, int(os.environ.get("BBME_CPU_THREADS", "16"))))
     legs = []
-    for name, flags, threads in (("st", [], 1), ("omp", ["-fopenmp"], usable)):
+    for name, flags, threads in (("st", [], 1), ("omp", ["-fopenmp"], pool)):
         out = os.path.join(tmp, "liboracle_native_%s.so" % name)
         subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-shared", "-ffp-contract=off"] + flags +
                               ["-o", out, src, "-lm"])
@@ -159,7 +161,12 @@ def main():
 
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
+    saved_stdout = None
     if use_dist:
+        # RCCL prints a version banner on stdout when a communicator is created; the contract is ONE JSON line there
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world,
@@ -420,7 +427,11 @@ def main():
                                                          "(calcLevelBM), regulariser sweeps sequential"},
                                    "host": {"cpu_model": model, "nproc": nproc, "usable_cores": usable}}
             out["parity_vs_oracle"] = bool(par1 and parn)
+        if saved_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
         print(json.dumps(out))
+        sys.stdout.flush()
     mf.close()
     if use_dist:
         dist.destroy_process_group()

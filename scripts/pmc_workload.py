@@ -26,6 +26,7 @@ _capi.check(_capi.lib().bbme_calibrate_read(0, a.calib_mib, 2))
 w, h, search, block, levels, _ = WORKLOADS[a.workload]
 f1, f2, _ = bbme.synth_pair(w, h, 1030, max_motion=24)
 mf = bbme.MF(f1, f2, [search] * levels, [block] * levels, levels)
+mf.set_speculation(False)        # one plain search launch per level, as in the eager pass bench.py's roofline comes from
 for _ in range(a.iters):
     mf.estimate_async()
     mf.synchronize()

@@ -10,6 +10,12 @@ timeout -k 10 300 python3 $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err || 
 echo "bench done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py --no-cpu-baseline --in-flight 0 > $OUT/stats.log 2>&1 || exit 1
 echo "stats done"
+# the same with the speculative overlap off: every k_search_fast launch is then a plain whole-level search, the kernel the
+# bench line's roofline object prices (its eager HIP-event pass never speculates)
+export BBME_SPECULATE=0
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_plain -- python3 $REPO/bench.py --no-cpu-baseline --in-flight 0 > $OUT/stats_plain.log 2>&1 || exit 1
+unset BBME_SPECULATE
+echo "stats (plain) done"
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/scripts/pmc_workload.py > $OUT/pmc_fetch.log 2>&1 || exit 1
 echo "pmc fetch done"
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $REPO/scripts/pmc_workload.py > $OUT/pmc_write.log 2>&1 || exit 1
