@@ -328,8 +328,10 @@ def main():
         from blockbasedmotionestimation_amd import _capi
         rates = (C.c_double * 4)()
         _capi.check(_capi.lib().bbme_probe_rates(local_rank, rates))
-        qsad_peak = rates[0] * 64 * 16 / 1e3          # T abs-diff/s through v_qsad_pk_u16_u8 (what the kernel uses)
+        qsad_peak = rates[0] * 64 * 16 / 1e3          # T abs-diff/s through v_qsad_pk_u16_u8, all operands in VGPRs
         sad_peak = rates[1] * 64 * 4 / 1e3            # T abs-diff/s through v_sad_u8
+        loops = (C.c_double * 2)()
+        _capi.check(_capi.lib().bbme_probe_search_loops(local_rank, loops))
         value = units * args.steps / elapsed / 1e6
         # dominant kernel: k_search_generic<B>, one launch per level.  Algorithmic bytes per block
         # = B^2 + (B+2R)^2 + 8; "per launch" = mean over the `levels` launches of a pyramid.
@@ -363,8 +365,12 @@ def main():
                          "binding": {"unit": "T abs-diff/s", "achieved": round(tabs, 3), "peak": VALU_SAD_PEAK_T,
                                      "frac": round(tabs / VALU_SAD_PEAK_T, 5),
                                      "peak_source": "spec: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz x 4 abs-diff per v_sad_u8 lane-op",
-                                     "measured_ceilings_Tabsdiff_s": {"v_qsad_pk_u16_u8": round(qsad_peak, 2), "v_sad_u8": round(sad_peak, 2)},
-                                     "frac_of_measured_qsad_ceiling": round(tabs / qsad_peak, 5),
+                                     "measured_ceilings_Tabsdiff_s": {
+                                         "v_qsad_pk_u16_u8 issue rate, VGPR operands": round(qsad_peak, 2),
+                                         "v_sad_u8 issue rate": round(sad_peak, 2),
+                                         "qsad strip loop (the kernel's inner loop alone: LDS rows + QSADs, block in SGPRs)": round(loops[0], 2),
+                                         "v_sad_u8 loop on four pre-shifted window copies (27 KB LDS per wave)": round(loops[1], 2)},
+                                     "frac_of_qsad_strip_loop": round(tabs / loops[0], 5),
                                      "level0_launch": {"ms": round(prof["search_level0_ms"], 4),
                                                        "achieved": round(blocks[0] * (2 * R + 1) ** 2 * block * block / (prof["search_level0_ms"] * 1e-3) / 1e12, 3)}},
                          "xcd_round_robin": xcd_check},

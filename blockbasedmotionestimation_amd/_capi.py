@@ -93,6 +93,7 @@ SIGNATURES = {
     "bbme_set_profiling": (C.c_int, [_ctx, C.c_int]),
     "bbme_get_timings": (C.c_int, [_ctx] + [_P(C.c_float)] * 5),
     "bbme_probe_rates": (C.c_int, [C.c_int, _P(C.c_double)]),
+    "bbme_probe_search_loops": (C.c_int, [C.c_int, _P(C.c_double)]),
     "bbme_probe_latency": (C.c_int, [C.c_int, _P(C.c_ulonglong)]),
     "bbme_probe_xcd": (C.c_int, [C.c_int, _P(C.c_int), _P(C.c_int)]),
     "bbme_set_search_mode": (C.c_int, [_ctx, C.c_int]),

@@ -993,6 +993,36 @@ int bbme_probe_rates(int device, double *gops)
     return BBME_OK;
 }
 
+int bbme_probe_search_loops(int device, double *tabs2)
+{
+    if (!tabs2) return bbme::fail(BBME_ERR_INVALID, "null output");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return bbme::fail(BBME_ERR_HIP, "no HIP device %d", device);
+    HIP_TRY(hipSetDevice(device));
+    uint32_t *out = nullptr;
+    HIP_TRY(hipMalloc(&out, 64));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    const int passes = 128, grid = 32768;
+    for (int which = 0; which < 2; ++which) {
+        for (int rep = 0; rep < 2; ++rep) {
+            HIP_TRY(hipEventRecord(e0, 0));
+            if (which == 0) hipLaunchKernelGGL(k_probe_search_loop<false>, dim3(grid), dim3(64), 6912 + 21 * 32 * 4, 0, out, passes, 3u + rep);
+            else hipLaunchKernelGGL(k_probe_search_loop<true>, dim3(grid), dim3(64), 27648 + 16 * 5 * 32 + 16 * 5 * 31, 0, out, passes, 3u + rep);
+            HIP_TRY(hipEventRecord(e1, 0));
+            HIP_TRY(hipEventSynchronize(e1));
+        }
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        // abs-diffs: per lane and pass 16 x 16 x 4 instructions of 16 (QSAD: four dx at once) or 4 (v_sad_u8) abs-diffs
+        const double absdiff = (double)grid * 64 * passes * 1024 * (which == 0 ? 16 : 4);
+        tabs2[which] = absdiff / (ms * 1e-3) / 1e12;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(out);
+    return BBME_OK;
+}
+
 int bbme_probe_latency(int device, unsigned long long *out9)
 {
     if (!out9) return bbme::fail(BBME_ERR_INVALID, "null output");

@@ -21,6 +21,9 @@ __device__ __forceinline__ int mv_x(mv_t m) { return (int)(int16_t)(m & 0xffffu)
 __device__ __forceinline__ int mv_y(mv_t m) { return (int)(int16_t)(m >> 16); }
 __device__ __forceinline__ mv_t mv_pack(int x, int y) { return ((uint32_t)x & 0xffffu) | ((uint32_t)y << 16); }
 
+// 16 bytes at any byte address (gfx950 global loads need no alignment; bbme_selftest_isa checks it)
+struct __attribute__((packed, aligned(1))) ua_u128 { uint32_t v[4]; };
+
 // =======================================================================================
 // K1 (generic form): MF::copyMVs + MF::calcLevelBM + MF::find_min_block_spiral
 // (motion_framework.cpp:828-843, 226-244, 296-422).  One wavefront per macroblock.
@@ -256,19 +259,23 @@ __device__ __forceinline__ uint32_t search_strip(const uint32_t *win, int P, con
     // One window row ahead is kept in flight.  The QSAD chains are pure, so the optimiser would
     // sink all of them below all of the LDS reads (150+ live VGPRs, occupancy gone); the empty asm
     // statements pin the order: reads of row yy+1, then the QSADs of row yy, row after row.
+    // QSAD's first operand is the 8 window bytes at dword q of the row: dwords (q, q + 1) in one register pair.  Adjacent
+    // operands overlap by a dword, so building them from BW + 1 loaded dwords costs a register copy each; loading every
+    // pair on its own (ds_read2_b32 q, q + 1 straight into the pair) costs LDS reads instead, which are not the limit.
+    struct __attribute__((packed, aligned(4))) pair_t { unsigned long long v; };
     const uint32_t *wrow = win + dy0 * P + g;
-    uint32_t wn[BW + 1];
+    unsigned long long wn[BW];
 #pragma unroll
-    for (int q = 0; q <= BW; ++q) wn[q] = wrow[q];
+    for (int q = 0; q < BW; ++q) wn[q] = reinterpret_cast<const pair_t *>(wrow + q)->v;
     wrow += P;
 #pragma unroll
     for (int yy = 0; yy < B + S - 1; ++yy) {
-        uint32_t w[BW + 1];
+        unsigned long long w[BW];
 #pragma unroll
-        for (int q = 0; q <= BW; ++q) w[q] = wn[q];
+        for (int q = 0; q < BW; ++q) w[q] = wn[q];
         if (yy + 1 < B + S - 1) {
 #pragma unroll
-            for (int q = 0; q <= BW; ++q) wn[q] = wrow[q];
+            for (int q = 0; q < BW; ++q) wn[q] = reinterpret_cast<const pair_t *>(wrow + q)->v;
             wrow += P;
         }
         asm volatile("" ::: "memory");
@@ -280,10 +287,8 @@ __device__ __forceinline__ uint32_t search_strip(const uint32_t *win, int P, con
             // instead of letting the compiler keep all 256 dwords of the block in VGPRs
             if constexpr (WIDE) asm volatile("" ::: "memory");
 #pragma unroll
-            for (int q = 0; q < BW; ++q) {
-                const unsigned long long pair = ((unsigned long long)w[q + 1] << 32) | w[q];
-                acc[d] = __builtin_amdgcn_qsad_pk_u16_u8(pair, cur.at(brow, q), acc[d]);
-            }
+            for (int q = 0; q < BW; ++q)
+                acc[d] = __builtin_amdgcn_qsad_pk_u16_u8(w[q], cur.at(brow, q), acc[d]);
             if constexpr (WIDE) {
                 if ((brow % FLUSH) == FLUSH - 1) {
                     const uint32_t lo = (uint32_t)acc[d], hi = (uint32_t)(acc[d] >> 32);
@@ -353,8 +358,37 @@ __device__ __forceinline__ void search_block_fast(const FastSearchArgs &a, uint3
     const int wx0 = px - R, wy0 = py - R;
     const int ax0 = wx0 & ~3, sh0 = wx0 & 3;
 
-    // stage the window: lane (rr, k) produces dword k of rows rr, rr + RPI, ... re-aligned by sh0 bytes
-    {
+    // stage the window.  Inside the image (the common case): 16-byte loads straight from the unaligned address wx0 --
+    // gfx950 global loads take any byte address, so the re-alignment costs nothing -- a lane owns a 4-dword chunk of a
+    // row, and the chunks of up to 8 passes are in flight together: the whole window in one memory trip.
+    const int wbytes = 4 * P;
+    if (wx0 >= 0 && wx0 + wbytes <= a.width && wy0 >= 0 && wy0 + wrows <= a.height) {
+        const int nch = (P + 3) >> 2;                        // chunks per row, the last one partial
+        const int rpp = 64 / nch;                            // rows per pass
+        const int rr = lane / nch, ch = lane - rr * nch;
+        const int nd = min(4, P - 4 * ch);                   // dwords of this lane's chunk that belong to the row
+        const uint8_t *src = a.image2 + (size_t)(wy0 + rr) * a.width + wx0 + 16 * ch;
+        uint32_t *dstw = smem + rr * P + 4 * ch;
+        const size_t sstep = (size_t)rpp * a.width;
+        const int dstep = rpp * P;
+        constexpr int U = 8;
+        for (int row0 = rr; row0 < wrows; row0 += rpp * U) {
+            ua_u128 v[U];
+#pragma unroll
+            for (int t = 0; t < U; ++t)
+                if (rr < rpp && row0 + t * rpp < wrows) v[t] = *reinterpret_cast<const ua_u128 *>(src + t * sstep);
+#pragma unroll
+            for (int t = 0; t < U; ++t)
+                if (rr < rpp && row0 + t * rpp < wrows) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (q < nd) dstw[t * dstep + q] = v[t].v[q];
+                }
+            src += U * sstep;
+            dstw += U * dstep;
+        }
+    } else {
+        // near the image border: lane (rr, k) produces dword k of rows rr, rr + RPI, ... re-aligned by sh0 bytes, zeros outside
         const int rpi = 64 / P;                              // rows per pass
         const int rr = lane / P, k = lane - rr * P;
         if (rr < rpi) {
@@ -378,11 +412,17 @@ __device__ __forceinline__ void search_block_fast(const FastSearchArgs &a, uint3
     CurBlock<B> cur;
     cur.lds = smem + wrows * P;
     if constexpr (B <= 16) {
+        // wave-uniform addresses of read-only data: through the constant address space these are scalar loads
+        // (s_load_dwordx4 per block row) instead of a vector load + v_readfirstlane per dword
+        typedef const uint32_t __attribute__((address_space(4))) *cptr_t;
+        const uint64_t base = (uint64_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uintptr_t)a.image1 >> 32)) << 32 |
+                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)a.image1);
+        const uint32_t off0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)i * (uint32_t)a.width + (uint32_t)j));
 #pragma unroll
         for (int r = 0; r < B; ++r) {
-            const uint32_t *c1 = reinterpret_cast<const uint32_t *>(a.image1 + (size_t)(i + r) * a.width + j);
+            cptr_t c1 = (cptr_t)(base + off0 + (uint32_t)r * (uint32_t)a.width);
 #pragma unroll
-            for (int q = 0; q < BW; ++q) cur.sg[r][q] = __builtin_amdgcn_readfirstlane(c1[q]);
+            for (int q = 0; q < BW; ++q) cur.sg[r][q] = c1[q];
         }
     } else {
         for (int idx = lane; idx < B * BW; idx += 64) {
@@ -1236,8 +1276,6 @@ __global__ __launch_bounds__(256) void k_epe(const mv_t *cells, int cell_cols, i
 // =======================================================================================
 struct PlanePair { const uint8_t *src[2]; uint8_t *dst[2]; };
 
-struct __attribute__((packed, aligned(1))) ua_u128 { uint32_t v[4]; };
-
 __global__ __launch_bounds__(256) void k_pad_zero(PlanePair p, int width, int height, int pitch,
                                                   int pad_x, int pad_y, int pw, int ph)
 {
@@ -1401,6 +1439,82 @@ __global__ __launch_bounds__(256) void k_probe_rate(uint32_t *out, int iters, ui
         for (int i = 0; i < 8; ++i) r ^= qa[i] ^ sa[i];
         if (r == 0x123456789abcdefull) out[0] = 1;
     }
+}
+
+// The two candidate inner loops of the search, stripped to their LDS reads and SAD instructions, at the occupancy their
+// LDS footprints allow (bbme_probe_search_loops): one wave per workgroup, a 16 x 16 block against an (16+64)^2 window.
+//   QSAD   (what k_search_fast does): window once in LDS (6.7 KB), a lane owns 4 adjacent dx x a strip of 16 rows; per
+//          window row 5 dword reads feed 64 v_qsad_pk_u16_u8 (16 abs-diff per lane each).
+//   SADU8  (the alternative VERDICT r01 asked to measure): v_sad_u8 issues 5x faster than QSAD but needs its window
+//          operand dword-aligned, so the window is kept in four copies shifted by 0..3 bytes (27 KB); a lane owns one dx
+//          x a strip of 16 rows; per window row one 16-byte read feeds 64 v_sad_u8 (4 abs-diff per lane each).
+// A pass is one strip round of the real kernel: 31 window rows, candidate row d meets block row yy - d (16 x 16 x 4 SAD
+// instructions per lane); accumulators are folded into `out`.
+template <bool SADU8>
+__global__ __launch_bounds__(64) void k_probe_search_loop(uint32_t *out, int passes, uint32_t seed)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int lane = threadIdx.x;
+    const int words = SADU8 ? 27 * 256 : 1728;                              // 27 KB / 6.75 KB
+    for (int i = lane; i < words; i += 64) smem[i] = (i + seed) * 2654435761u;
+    __syncthreads();
+    uint32_t cur[16][4];                                                    // the 16 x 16 block, wave-uniform (SGPRs)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[r][q] = __builtin_amdgcn_readfirstlane((seed + 16 * r + q) * 40503u);
+    uint32_t fold = 0;
+    for (int p = 0; p < passes; ++p) {
+        // one strip round: 31 window rows; candidate row d of the strip meets block row yy - d (as search_strip)
+        if constexpr (!SADU8) {
+            unsigned long long acc[16];
+#pragma unroll
+            for (int d = 0; d < 16; ++d) acc[d] = 0;
+            const uint32_t *wrow = smem + (lane & 15) + 21 * (p & 31);
+#pragma unroll
+            for (int yy = 0; yy < 31; ++yy) {
+                uint32_t w[5];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) w[q] = wrow[q];
+                wrow += 21;
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int d = 0; d < 16; ++d) {
+                    const int brow = yy - d;
+                    if (brow < 0 || brow >= 16) continue;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc[d] = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)w[q + 1] << 32) | w[q], cur[brow][q], acc[d]);
+                    asm volatile("" : "+v"(acc[d]));
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < 16; ++d) fold ^= (uint32_t)acc[d] ^ (uint32_t)(acc[d] >> 32);
+        } else {
+            uint32_t acc[16];
+#pragma unroll
+            for (int d = 0; d < 16; ++d) acc[d] = 0;
+            const uint4 *wrow = reinterpret_cast<const uint4 *>(smem) + (lane & 3) * 432 + (lane >> 2) + 5 * (p & 31);
+#pragma unroll
+            for (int yy = 0; yy < 31; ++yy) {
+                const uint4 w = wrow[5 * yy];
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int d = 0; d < 16; ++d) {
+                    const int brow = yy - d;
+                    if (brow < 0 || brow >= 16) continue;
+                    acc[d] = __builtin_amdgcn_sad_u8(w.x, cur[brow][0], acc[d]);
+                    acc[d] = __builtin_amdgcn_sad_u8(w.y, cur[brow][1], acc[d]);
+                    acc[d] = __builtin_amdgcn_sad_u8(w.z, cur[brow][2], acc[d]);
+                    acc[d] = __builtin_amdgcn_sad_u8(w.w, cur[brow][3], acc[d]);
+                    asm volatile("" : "+v"(acc[d]));
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < 16; ++d) fold ^= acc[d];
+        }
+    }
+    if (fold == 0x12345678u) out[0] = fold;                                  // keeps the work alive
 }
 
 // dependent-chain latencies of the memory operations the solver round is made of (one wave, one lane

@@ -227,6 +227,12 @@ int bbme_get_timings(bbme_ctx *ctx, float *total_ms, float *search_ms, float *re
  * is interleaved with one / four independent v_sad_u8 (do the two instructions overlap?). */
 int bbme_probe_rates(int device, double *gops);
 
+/* The two candidate inner loops of the search kernel, reduced to their LDS reads and SAD instructions and run at the
+ * occupancy their LDS footprints allow: tabs[0] = v_qsad_pk_u16_u8 strips over one copy of the window (what k_search_fast
+ * does, 6.75 KB per wave), tabs[1] = v_sad_u8 over four byte-shifted copies (27 KB per wave), in 1e12 abs-diff per second.
+ * The measurement behind the choice of instruction. */
+int bbme_probe_search_loops(int device, double *tabs2);
+
 /* Dependent-chain latency of the memory operations a solver round is made of, one lane on an idle
  * chip: out[2k] = shader cycles per operation, out[2k+1] = 10 ns ticks for 256 operations, for
  * k = 0 plain load, 1 agent-scope load, 2 returning atomic, 3 agent-scope store + drain. */
