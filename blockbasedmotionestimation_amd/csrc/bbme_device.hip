@@ -35,6 +35,7 @@ struct Level {
     mv_t *cur_grid = nullptr;                     // the grid that holds the current field
     int cur_block = 0;                            // its block size (0 = nothing yet)
     mv_t *pred = nullptr;                         // per block: the coarse MV a speculative search started from
+    uint32_t *fix_list = nullptr, *fix_count = nullptr;   // blocks to search again after a speculative search
     mv_t *final_grid() const { return block == 2 ? small[0] : big[1]; }   // where two sweeps per block size leave the 2x2 cells
     uint32_t *spiral = nullptr;                   // rank -> packed (dx, dy)
     int ncand = 0;
@@ -183,6 +184,18 @@ int launch_search_fast(bbme_ctx *c, int level, int mode, hipStream_t stream, siz
     a.xcd_remap = c->xcd_remap;
     const int grid = c->xcd_remap ? ((nblocks + 7) / 8) * 8 : nblocks;
     const size_t lds = std::max(L.fast_lds_bytes, lds_floor);
+    a.fix_count = L.fix_count;
+    if (mode == kSearchFixup && a.coarse) {
+        // list the blocks whose prediction changed, then search those (k_fixup_list, k_search_list)
+        a.mode = kSearchPlain;
+        hipLaunchKernelGGL(k_fixup_list, dim3((nblocks + 255) / 256), dim3(256), 0, stream, a, L.block, L.fix_count, L.fix_list);
+        const int lgrid = std::max(64, nblocks / 4);
+        if (L.block == 16) hipLaunchKernelGGL(k_search_list<16>, dim3(lgrid), dim3(64), lds, stream, a, L.fix_count, L.fix_list);
+        else if (L.block == 32) hipLaunchKernelGGL(k_search_list<32>, dim3(lgrid), dim3(64), lds, stream, a, L.fix_count, L.fix_list);
+        else hipLaunchKernelGGL(k_search_list<8>, dim3(lgrid), dim3(64), lds, stream, a, L.fix_count, L.fix_list);
+        HIP_TRY(hipGetLastError());
+        return BBME_OK;
+    }
     if (L.block == 16)
         hipLaunchKernelGGL(k_search_fast<16>, dim3(grid), dim3(64), lds, stream, a);
     else if (L.block == 32)
@@ -342,8 +355,12 @@ int launch_expand(bbme_ctx *c)
 int enqueue_pyramid(bbme_ctx *c, bool speculate)
 {
     const int nl = (int)c->lv.size();
-    if (speculate && nl > 1 && !c->side_stream)         // only contexts that speculate hold a second stream (hardware queue)
-        HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    if (speculate && nl > 1 && !c->side_stream) {       // only contexts that speculate hold a second stream (hardware queue)
+        // lowest dispatch priority: the regulariser's workgroups on the main stream go first whenever both have some ready
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, lo));
+    }
     bool speculated = false;
     for (int l = nl - 1; l >= 0; --l) {
         if (speculated) {
@@ -482,6 +499,9 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
             (err = hipMalloc(&L.small[0], own_blocks * sizeof(mv_t))) != hipSuccess ||
             (err = hipMalloc(&L.small[1], own_blocks * sizeof(mv_t))) != hipSuccess ||
             (err = hipMalloc(&L.pred, own_blocks * sizeof(mv_t))) != hipSuccess ||
+            (err = hipMalloc(&L.fix_list, own_blocks * sizeof(uint32_t))) != hipSuccess ||
+            (err = hipMalloc(&L.fix_count, 64)) != hipSuccess ||
+            (err = hipMemset(L.fix_count, 0, 64)) != hipSuccess ||
             (err = hipMalloc(&L.big[0], cells * sizeof(mv_t))) != hipSuccess ||
             (err = hipMalloc(&L.big[1], cells * sizeof(mv_t))) != hipSuccess ||
             (err = hipMalloc(&L.spiral, packed.size() * 4)) != hipSuccess ||
@@ -539,6 +559,7 @@ int bbme_destroy(bbme_ctx *c)
     for (Level &L : c->lv) {
         (void)hipFree(L.img1); (void)hipFree(L.img2);
         (void)hipFree(L.small[0]); (void)hipFree(L.small[1]); (void)hipFree(L.pred);
+        (void)hipFree(L.fix_list); (void)hipFree(L.fix_count);
         (void)hipFree(L.big[0]); (void)hipFree(L.big[1]); (void)hipFree(L.spiral);
         (void)hipFree(L.rank_of); (void)hipFree(L.tasks); (void)hipFree(L.rounds);
     }

@@ -214,6 +214,7 @@ struct FastSearchArgs {
     int coarse_cols, coarse_block, coarse_cell_shift;
     int mode;
     mv_t *pred;
+    uint32_t *fix_count;        // length of the fix-up list (zeroed by the speculative launch)
     mv_t *out;
     int cols;
     int pitch_dw;               // LDS window pitch in dwords (odd)
@@ -466,10 +467,50 @@ __global__ __launch_bounds__(64) void k_search_fast(FastSearchArgs a)
     // 80 % -- meet in the same L2.  Pure speed: any placement gives the same result.
     const uint32_t chunk = (uint32_t)(a.nblocks + 7) / 8;
     const uint32_t bid = a.xcd_remap ? (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3) : blockIdx.x;
+    if (a.mode == kSearchSpeculative && blockIdx.x == 0 && threadIdx.x == 0) *a.fix_count = 0;   // for the fix-up behind this launch
     if (bid >= (uint32_t)a.nblocks) return;
     mv_t m;                                                 // copyMVs (:828-843)
     if (!search_prediction(a, (int)(bid / (uint32_t)a.cols) * B, (int)(bid % (uint32_t)a.cols) * B, bid, m)) return;
     search_block_fast<B>(a, bid, m, smem);
+}
+
+// The fix-up behind a speculative search, in two launches (one workgroup per macroblock that mostly returns at once costs
+// more in dispatch than the searches that remain): k_fixup_list compares every block's final prediction with the one the
+// speculative search used and appends the blocks that differ to a list (one atomic per workgroup); k_search_list searches
+// the listed blocks, workgroup w taking entries w, w + gridDim.x, ...  The speculative launch zeroes the list's counter.
+__global__ __launch_bounds__(256) void k_fixup_list(FastSearchArgs a, int block, uint32_t *count, uint32_t *list)
+{
+    __shared__ uint32_t s_n, s_base;
+    const uint32_t bid = blockIdx.x * 256 + threadIdx.x;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    bool redo = false;
+    if (bid < (uint32_t)a.nblocks) {
+        const int i = (int)(bid / (uint32_t)a.cols) * block, j = (int)(bid % (uint32_t)a.cols) * block;
+        const int ci = (i / (2 * a.coarse_block)) * a.coarse_block, cj = (j / (2 * a.coarse_block)) * a.coarse_block;
+        const mv_t m = a.coarse[(size_t)(ci >> a.coarse_cell_shift) * a.coarse_cols + (cj >> a.coarse_cell_shift)];
+        redo = a.pred[bid] != m;
+    }
+    uint32_t slot = 0;
+    if (redo) slot = atomicAdd(&s_n, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) s_base = atomicAdd(count, s_n);
+    __syncthreads();
+    if (redo) list[s_base + slot] = bid;
+}
+
+template <int B>
+__global__ __launch_bounds__(64) void k_search_list(FastSearchArgs a, const uint32_t *count, const uint32_t *list)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t n = *count;
+    for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {               // wave-uniform
+        const uint32_t bid = list[e];
+        mv_t m;
+        (void)search_prediction(a, (int)(bid / (uint32_t)a.cols) * B, (int)(bid % (uint32_t)a.cols) * B, bid, m);   // a.mode == kSearchPlain
+        search_block_fast<B>(a, bid, m, smem);
+        __syncthreads();                                                   // the window in LDS is re-used
+    }
 }
 
 // =======================================================================================

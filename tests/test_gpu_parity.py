@@ -19,6 +19,19 @@ def test_isa_probes(bbme):
     assert list(mism) == [0] * 5, "sad_u8, alignbyte, qsad_pk_u16_u8, sad_u16, unaligned loads: %s" % list(mism)
 
 
+def test_device_probes(bbme):
+    """The measurements bench.py quotes come from these entry points: the XCD round-robin check behind the XCD-aware block
+    orders (8 XCDs, no workgroup off its residue class) and the two search inner loops (both must report a rate)."""
+    import ctypes as C
+    from blockbasedmotionestimation_amd import _capi
+    seen, viol = C.c_int(), C.c_int()
+    _capi.check(_capi.lib().bbme_probe_xcd(0, C.byref(seen), C.byref(viol)))
+    assert seen.value == 8 and viol.value == 0
+    t = (C.c_double * 2)()
+    _capi.check(_capi.lib().bbme_probe_search_loops(0, t))
+    assert 20 < t[0] < 400 and 20 < t[1] < 400
+
+
 CASES = [
     # (width, height, search_size[], block_size[], seed, max_motion)
     (320, 208, [30, 30, 30], [16, 16, 16], 1001, 12),          # cfg1-like: B=16, R=7, 3 levels

@@ -168,6 +168,31 @@ def test_motion_to_color_equals_oracle(bbme, oracle, tmp_path, capsys):
     assert e.value.status == -6
 
 
+def test_async_flow_writer(bbme, tmp_path):
+    """bbme_flo_writer_* (SURVEY 8f3): files written on the worker thread are byte for byte Flow::WriteFlowFile's, for a
+    whole field and for the unpadded window of a padded one (main_class.cpp:63-70); I/O errors surface at wait()."""
+    rng = np.random.default_rng(0)
+    f = rng.standard_normal((40, 56, 2)).astype(np.float32)
+    w = bbme.FlowWriter()
+    w.submit(f, str(tmp_path / "a.flo"))
+    w.submit(f, str(tmp_path / "b.flo"), pad_x=4, pad_y=6, width=40, height=20)
+    w.wait()
+    assert np.array_equal(bbme.Flow().ReadFlowFile(str(tmp_path / "a.flo")), f)
+    bbme.Flow().WriteFlowFile(f[6:26, 4:44], str(tmp_path / "c.flo"))
+    assert (tmp_path / "b.flo").read_bytes() == (tmp_path / "c.flo").read_bytes()
+    with pytest.raises(bbme.BbmeError) as e:
+        w.submit(f, str(tmp_path / "b.txt"))                        # extension check of WriteFlowFile (:147-152)
+    assert e.value.status == -6
+    w.submit(f, str(tmp_path / "no_such_dir" / "x.flo"))
+    with pytest.raises(bbme.BbmeError) as e:
+        w.wait()
+    assert e.value.status == -6 and "problem writing" in e.value.message
+    w.submit(f, str(tmp_path / "d.flo"))                            # usable again after an error
+    w.wait()
+    assert (tmp_path / "d.flo").read_bytes() == (tmp_path / "a.flo").read_bytes()
+    w.close()
+
+
 def test_flow_errors_raise_instead_of_exit(bbme, tmp_path):
     flow = bbme.Flow()
     good = open(os.path.join(GOLDEN, "flo_ramp_ref.flo"), "rb").read()
