@@ -82,6 +82,7 @@ struct bbme_ctx {
     hipStream_t side_stream = nullptr;            // the speculative searches
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     size_t spec_lds = 0;                          // LDS per workgroup of a speculative search launch (occupancy cap)
+    double spec_min_absdiffs = 8e9;               // levels with less search work are not speculated; BBME_SPEC_MIN_GABS
     hipGraphExec_t graph_exec = nullptr;
     bool profiling = false;
     float t_total = 0, t_search = 0, t_reg = 0, t_expand = 0, t_search0 = 0;
@@ -348,6 +349,18 @@ int launch_expand(bbme_ctx *c)
     return BBME_OK;
 }
 
+// A speculative search pays its fork, its fix-up launches and the stretch it puts on the sweeps beside it only when the
+// search it hides is long: levels below ~8 G abs-diffs (~90 us) are searched in line (measured: cfg2, cfg1 and the reference's
+// literals lose 3-12 % when every level is speculated; cfg3 / cfg4 gain 8-10 % from their two largest levels).
+bool worth_speculating(const bbme_ctx *c, int level)
+{
+    if (c->jacobi) return false;                     // Jacobi sweeps are too short to hide a search behind
+    const Level &L = c->lv[level];
+    const double side = 2.0 * L.range + 1.0;
+    const double absdiffs = (double)(L.width / L.block) * (L.height / L.block) * side * side * L.block * L.block;
+    return absdiffs >= c->spec_min_absdiffs;
+}
+
 // The level loop of MF::calcMotionBlockMatching (:115-206).  With `speculate`, the search of level l-1 is started on a
 // second stream as soon as level l has finished the two sweeps at its own block size, and runs beside the level's
 // remaining sweeps (which are latency-bound and leave most of the chip idle); when the level is final, a fix-up launch
@@ -371,7 +384,7 @@ int enqueue_pyramid(bbme_ctx *c, bool speculate)
         for (int b = c->lv[l].block; b > 1; b >>= 1) {            // while (block_size > 1) :141
             for (int mult = 1; mult <= 2; ++mult)                  // lambda_multiplier = l + 1 :145
                 if (int rc = launch_sweep(c, l, b, mult)) return rc;
-            if (speculate && l > 0 && b == c->lv[l].block && b > 2) {
+            if (speculate && l > 0 && b == c->lv[l].block && b > 2 && worth_speculating(c, l - 1)) {
                 HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
                 HIP_TRY(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
                 if (int rc = launch_search(c, l - 1, kSearchSpeculative, c->side_stream, c->spec_lds)) return rc;
@@ -468,6 +481,7 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
         int per_cu = 8;
         if (const char *e = getenv("BBME_SPEC_WGS_PER_CU")) per_cu = std::max(1, std::min(32, atoi(e)));
         c->spec_lds = ((size_t)(160 - 40) * 1024 / per_cu) / 256 * 256;
+        if (const char *e = getenv("BBME_SPEC_MIN_GABS")) c->spec_min_absdiffs = atof(e) * 1e9;
     }
     if (const char *e = getenv("BBME_GENERIC_SEARCH")) c->force_generic_search = atoi(e) != 0;
     if (const char *e = getenv("BBME_XCD_REMAP")) c->xcd_remap = atoi(e) != 0;
