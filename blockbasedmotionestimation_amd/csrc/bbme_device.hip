@@ -72,7 +72,7 @@ struct bbme_ctx {
     bool frames_set = false;
     double *epe_scratch = nullptr;                // partial sums + counts of bbme_calculate_mse_device (allocated on first use)
     int solve_waves = 4;                          // waves per solver workgroup (1, 2 or 4); BBME_SOLVE_WAVES
-    int solve_wgs = 256;                          // most workgroups of k_reg_solve (4 independent waves each): one wave per SIMD
+    int solve_wgs = 128;                          // most workgroups of k_reg_solve (4 independent waves each): one wave per SIMD
     int xcd_remap = 1;                            // XCD-aware block order in k_search_fast; BBME_XCD_REMAP
     bool jacobi = false;                          // opt-in, not bit-exact: Jacobi sweeps (pass 1 only); bbme_set_regularizer_mode
     bool raster_search = false;                   // MF::find_min_block (:246-294) instead of the spiral search; bbme_set_search_mode
@@ -300,7 +300,7 @@ int launch_sweep(bbme_ctx *c, int level, int b, int mult)
     a.own_pitch = c->own_pitch;
     static const int rounds_env = getenv("BBME_LOCAL_ROUNDS") ? atoi(getenv("BBME_LOCAL_ROUNDS")) : 8;
     a.local_rounds = std::max(1, rounds_env);
-    static const int wide_env = getenv("BBME_WIDE_THRESHOLD") ? atoi(getenv("BBME_WIDE_THRESHOLD")) : 4;
+    static const int wide_env = getenv("BBME_WIDE_THRESHOLD") ? atoi(getenv("BBME_WIDE_THRESHOLD")) : 16;
     a.wide_threshold = (uint32_t)std::max(4, wide_env);
     // every round of a wave either empties part of its queue or follows a real change, and a change can only travel
     // along the raster dependency chain (< 2 * rows + cols blocks): the cap is an exit every wave reaches even if

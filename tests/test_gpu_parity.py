@@ -663,3 +663,28 @@ def test_jacobi_fast_mode_is_what_it_says(bbme, oracle):
     mf.set_regularizer_mode(False)
     assert np.array_equal(mf.calcMotionBlockMatching(), exact)
     mf.close()
+
+
+def test_8k_pair_schedule_independence(bbme):
+    """7680x4320, five levels (8.4 M 2x2 cells at level 0: every buffer, grid and list at four times the bench's size).  Too
+    large for the oracle to check in seconds, so the properties that hold for any correct schedule: the same field on a
+    second run, with the speculative search off, and with a single-wave solver; and the Jacobi mode differs."""
+    import os
+    f1, f2, _ = bbme.synth_pair(7680, 4320, 77, max_motion=24)
+    search, block = [80] * 5, [16] * 5
+    mf = bbme.MF(f1, f2, search, block, 5)
+    a = mf.calcMotionBlockMatching()
+    assert np.array_equal(mf.calcMotionBlockMatching(), a)
+    mf.set_speculation(False)
+    assert np.array_equal(mf.calcMotionBlockMatching(), a)
+    mf.set_regularizer_mode(True)
+    assert not np.array_equal(mf.calcMotionBlockMatching(), a)
+    mf.close()
+    assert (a == np.round(a)).all() and np.array_equal(a[::2, ::2], a[1::2, 1::2])       # integer MVs, constant on 2x2 cells
+    os.environ["BBME_SOLVE_WGS"], os.environ["BBME_SOLVE_WAVES"] = "8", "1"
+    try:
+        mf = bbme.MF(f1, f2, search, block, 5)
+    finally:
+        del os.environ["BBME_SOLVE_WGS"], os.environ["BBME_SOLVE_WAVES"]
+    assert np.array_equal(mf.calcMotionBlockMatching(), a)
+    mf.close()
