@@ -17,6 +17,10 @@
  *       here, so it cannot be built.  These functions follow the reference
  *       source line by line (citations on every function) and are
  *       cross-checked by an independent numpy restatement (oracle/bbme_numpy.py).
+ *   raster search find_min_block (:246-294, dead code in the reference; raster_search = 1) : PARITY UNPINNED, same
+ *       grounds; additionally checked against a direct numpy statement of its rules (tests/test_oracle_cpu.py).
+ *   jacobi_regularizer = 1 : NOT a reference function -- the written-down definition of the product's opt-in fast
+ *       mode, so that that mode can be tested bit for bit and its distance from the reference's field measured.
  *   padding / pyrDown / 4x bilinear resize : PARITY UNPINNED.  Restated from
  *       OpenCV's published 8-bit algorithms; outside the hot path (host prep).
  *
