@@ -49,10 +49,24 @@ CASES = {
 }
 
 
-def make_hotpath(name, w, h, search, block, seed, mm):
+# the variants of SURVEY 8(f4): "variant_*.npz", made with `python tests/golden/make_golden.py variants` (the files above
+# are not rewritten).  raster: MF::find_min_block (:246-294) as the search; jacobi: NOT the reference -- the product's
+# opt-in fast regulariser as the oracle defines it.
+VARIANTS = {
+    "variant_raster_b16_r7_l3": (160, 112, [30, 30, 30], [16, 16, 16], 2101, 6, "raster"),
+    "variant_raster_b8_r32_l2": (96, 64, [72, 72], [8, 8], 2102, 10, "raster"),
+    "variant_jacobi_b16_r7_l3": (160, 112, [30, 30, 30], [16, 16, 16], 2103, 6, "jacobi"),
+}
+
+
+def make_hotpath(name, w, h, search, block, seed, mm, mode=None):
     f1, f2, _ = synth_pair(w, h, seed, max_motion=mm)
     L = len(block)
     omf = O.OracleMF(f1, f2, search, block)
+    if mode == "raster":
+        omf.set_raster_search(True)
+    if mode == "jacobi":
+        omf.set_jacobi_regularizer(True)
     data = {"search_size": np.array(search, np.int32), "block_size": np.array(block, np.int32),
             "frame1": f1, "frame2": f2,
             "geometry": np.array([omf.padded_width, omf.padded_height, omf.padding_x, omf.padding_y], np.int32)}
@@ -90,6 +104,10 @@ def color_by_reference(flo_ref, flo_path, shape, maxmotion=None):
 
 def main():
     O.build(force=True)
+    if sys.argv[1:] == ["variants"]:
+        for name, cfg in VARIANTS.items():
+            make_hotpath(name, *cfg)
+        return
     for name, cfg in CASES.items():
         make_hotpath(name, *cfg)
     flo_ref = O.FLO_REF

@@ -68,7 +68,8 @@ def test_stagewise_parity(bbme, oracle, w, h, search, block, seed, mm):
 
 
 @pytest.mark.parametrize("name", ["hotpath_b16_r7_l3", "hotpath_b16_r16_l2", "hotpath_b8_r32_l2",
-                                  "hotpath_b32_r16_l2", "hotpath_mixed_l3"])
+                                  "hotpath_b32_r16_l2", "hotpath_mixed_l3",
+                                  "variant_raster_b16_r7_l3", "variant_raster_b8_r32_l2", "variant_jacobi_b16_r7_l3"])
 def test_golden_fixtures(bbme, name):
     """Committed vectors (tests/golden/*.npz): planes in, every intermediate MV grid and the final
     dense flow out.  No oracle call on this path."""
@@ -78,6 +79,8 @@ def test_golden_fixtures(bbme, name):
     block = g["block_size"].tolist()
     L = len(block)
     mf = bbme.MF(g["frame1"], g["frame2"], g["search_size"].tolist(), block, L)
+    mf.set_search_mode("raster" in name)
+    mf.set_regularizer_mode("jacobi" in name)
     assert [mf.padded_width, mf.padded_height, mf.padding_x, mf.padding_y] == g["geometry"].tolist()
     for lvl in range(L):
         mf.set_level_planes(lvl, g["plane1_l%d" % lvl], g["plane2_l%d" % lvl])

@@ -39,13 +39,18 @@ def test_spiral_walk_covers_square_once_and_matches_closed_form(oracle, shift):
 
 
 # ---- hot path: C oracle vs committed vectors vs numpy restatement --------------------------------
-@pytest.mark.parametrize("name", GOLDEN_CASES)
+VARIANT_CASES = ["variant_raster_b16_r7_l3", "variant_raster_b8_r32_l2", "variant_jacobi_b16_r7_l3"]
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES + VARIANT_CASES)
 def test_oracle_reproduces_golden_vectors(oracle, name):
     g = load_golden(name)
     L = len(g["block_size"])
     omf = oracle.OracleMF(planes1=[g["plane1_l%d" % l] for l in range(L)],
                           planes2=[g["plane2_l%d" % l] for l in range(L)],
                           search_size=g["search_size"].tolist(), block_size=g["block_size"].tolist())
+    omf.set_raster_search("raster" in name)
+    omf.set_jacobi_regularizer("jacobi" in name)
     got = []
     flow = oracle_schedule(omf, L, lambda kind, lvl, b, mv: got.append((kind, lvl, b, mv)))
     keys = [str(k) for k in g["stages"]]
@@ -56,6 +61,8 @@ def test_oracle_reproduces_golden_vectors(oracle, name):
     assert np.array_equal(g["flow"], flow)
     # and the one-call orchestrator gives the same field as the stage-by-stage drive
     omf2 = oracle.OracleMF(g["frame1"], g["frame2"], g["search_size"].tolist(), g["block_size"].tolist())
+    omf2.set_raster_search("raster" in name)
+    omf2.set_jacobi_regularizer("jacobi" in name)
     assert [omf2.padded_width, omf2.padded_height, omf2.padding_x, omf2.padding_y] == g["geometry"].tolist()
     assert np.array_equal(omf2.calc_motion_block_matching(), g["flow"])
 
