@@ -268,13 +268,7 @@ void launch_sweep_t(RegArgs a, uint8_t *const flags[2], int relax_steps, int max
         hipLaunchKernelGGL(k_reg_iter<BS>, dim3(tiles), dim3(256), 0, s, a);
     }
     a.flag_cur = flags[cur]; a.flag_next = nullptr;
-    if (a.xcd_experiment) {
-        // measurement only (BBME_XCD_EXPERIMENT): eight times the workgroups, of which the ones on XCD 0 work
-        if (a.xcd_experiment == 2) hipLaunchKernelGGL((k_reg_solve<BS, true>), dim3(grid2 * 8), dim3(64 * solve_waves), 0, s, a);
-        else hipLaunchKernelGGL((k_reg_solve<BS, false>), dim3(grid2 * 8), dim3(64 * solve_waves), 0, s, a);
-        return;
-    }
-    hipLaunchKernelGGL((k_reg_solve<BS, false>), dim3(grid2), dim3(64 * solve_waves), 0, s, a);
+    hipLaunchKernelGGL(k_reg_solve<BS>, dim3(grid2), dim3(64 * solve_waves), 0, s, a);
 }
 
 int launch_sweep(bbme_ctx *c, int level, int b, int mult)
@@ -313,8 +307,6 @@ int launch_sweep(bbme_ctx *c, int level, int b, int mult)
     // that reasoning were wrong; hitting it raises counters[5] and the result is refused (BBME_ERR_STATE)
     a.round_cap = c->round_cap > 0 ? (uint32_t)c->round_cap : 64u * (uint32_t)(2 * a.rows + a.cols + 16);
     a.counters = c->counters;
-    static const int xcd_exp = getenv("BBME_XCD_EXPERIMENT") ? atoi(getenv("BBME_XCD_EXPERIMENT")) : 0;
-    a.xcd_experiment = xcd_exp;
     // relaxation launches (k_reg_iter, 8 local rounds per tile): one more launch (>= 5 us), which only the sweeps with
     // heavy first generations repay -- measured on cfg3 / cfg4 / cfg2: large grids of small blocks, one launch per sweep
     const long long nblk = (long long)a.rows * a.cols;

@@ -551,7 +551,6 @@ struct RegArgs {
     int local_rounds;           // k_reg_iter: rounds a workgroup runs on its tile within one launch
     uint32_t wide_threshold;    // solver: queue length above which a round uses the throughput form
     uint32_t round_cap;         // most rounds / idle spins of one wave before it gives up and raises counters[5]
-    int xcd_experiment;         // 0; 1 / 2: the solver on one XCD with agent-scope / XCD-local operations (measurement only)
     uint32_t *counters;         // [0..2] overflow list lengths (rotating), [3] safety-net passes, [4] blocks re-evaluated,
                                 // [5] sticky: a sweep hit a cap without converging, [6] solver ticket, [7] most rounds of
                                 // one wave, [8] rounds summed, [9..15] phase profile
@@ -858,26 +857,13 @@ __device__ __forceinline__ mv_t eval_block_lanes(const RegArgs &a, int r, int c,
 // (mod 256) apart: different cache lines on different L2 channels, instead of 32 atomics queueing
 // on one line.
 __device__ __forceinline__ uint32_t own_slot(const RegArgs &a, uint32_t x) { return (x & 31u) * a.own_pitch + (x >> 5); }
-// XL (the XCD-local experiment, BBME_XCD_EXPERIMENT=2): every solver wave runs on ONE XCD, so its L2 is the
-// point of coherence -- atomics at workgroup scope execute in that L2 instead of at the memory side of the fabric, estimates
-// are stored plainly (the line stays in that L2) and still loaded around the L1 (sc1).
-template <bool XL = false>
 __device__ __forceinline__ uint32_t own_claim(const RegArgs &a, uint32_t x)    // returns the old counter
 {
-    if constexpr (XL) return __hip_atomic_fetch_add(&a.own[own_slot(a, x)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else return atomicAdd(&a.own[own_slot(a, x)], 1u);
+    return atomicAdd(&a.own[own_slot(a, x)], 1u);
 }
-template <bool XL = false>
 __device__ __forceinline__ uint32_t own_release(const RegArgs &a, uint32_t x)  // returns the old counter
 {
-    if constexpr (XL) return __hip_atomic_exchange(&a.own[own_slot(a, x)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else return atomicExch(&a.own[own_slot(a, x)], 0u);
-}
-template <bool XL = false>
-__device__ __forceinline__ void store_est(mv_t *p, mv_t v)
-{
-    if constexpr (XL) *(volatile mv_t *)p = v;
-    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return atomicExch(&a.own[own_slot(a, x)], 0u);
 }
 #define BBME_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
@@ -1037,7 +1023,7 @@ __global__ __launch_bounds__(256) void k_reg_iter(RegArgs a)
 
 // One work-list pass of the safety net (see k_reg_solve's epilogue): `nthreads` threads of one
 // workgroup, lists in global memory that cannot overflow (a block is on a list at most once).
-template <int BS, bool XL = false>
+template <int BS>
 __device__ __forceinline__ void drain_lists(const RegArgs &a, int t, int nthreads)
 {
     constexpr int LPB = 16;                      // lane k of a group = candidate k (eval_block_lanes)
@@ -1063,11 +1049,11 @@ __device__ __forceinline__ void drain_lists(const RegArgs &a, int t, int nthread
         for (uint32_t idx = group; idx < n; idx += ngroups) {
             const uint32_t x = __hip_atomic_load(&lcur[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int r = (int)(x / a.cols), c = (int)(x % a.cols);
-            if (sub == 0) own_release<XL>(a, x);                                  // the list owned it
+            if (sub == 0) own_release(a, x);                                  // the list owned it
             BBME_DRAIN();
             const mv_t res = eval_block_lanes<BS, true>(a, r, c, sub, BBME_NEW_MASK);
             if (sub == 0 && res != load_est<true>(a.est + x)) {
-                store_est<XL>(a.est + x, res);
+                __hip_atomic_store(a.est + x, res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 BBME_DRAIN();
                 const int dr[4] = {0, 1, 1, 1}, dc[4] = {1, 1, 0, -1};
 #pragma unroll
@@ -1075,7 +1061,7 @@ __device__ __forceinline__ void drain_lists(const RegArgs &a, int t, int nthread
                     const int rr = r + dr[d], cc = c + dc[d];
                     if (rr >= a.rows || cc < 0 || cc >= a.cols) continue;
                     const uint32_t xd = (uint32_t)rr * a.cols + cc;
-                    if (own_claim<XL>(a, xd) == 0)
+                    if (own_claim(a, xd) == 0)
                         __hip_atomic_store(&lnext[atomicAdd(cnext, 1u)], xd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
@@ -1102,7 +1088,7 @@ __device__ __forceinline__ void drain_lists(const RegArgs &a, int t, int nthread
 // s belongs to wave s mod W of that XCD, so that a cluster of stale blocks is spread over many waves
 // instead of queueing up behind one, and a wave looks at 64 of its segments -- 1024 flags -- per memory
 // trip: a sweep that left nothing stale costs two trips at 2 M blocks, not 127.
-template <int BS, bool XL = false>
+template <int BS>
 __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
 {
     // two forms of a round: WIDE (eval_block: LPBW lanes per block, 64/LPBW blocks per round) when
@@ -1152,24 +1138,12 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
         }
     };
 
-    // one-XCD experiment (a.xcd_experiment != 0: with agent-scope operations = 1, with XCD-local ones = 2): only the waves on
-    // XCD 0 (HW_REG_XCC_ID, read, not assumed) take part; they share the whole map, 64 segments per grab of a counter
-    const bool one_xcd = a.xcd_experiment != 0;
-    const bool idle_xcd = one_xcd && ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu) != 0u;
-    bool more = !idle_xcd;
-    for (uint32_t k = 0; !idle_xcd; ++k) {
-        uint32_t chunk = 0;
-        if (one_xcd && more) {
-            if (lane == 0) chunk = atomicAdd(&a.counters[10], 1u);
-            chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk);
-            more = chunk * 64u < nseg;
-        }
-        if (one_xcd ? more : (seg_begin + k * 64u * Wx + wx < seg_end)) {
-            const uint32_t sg = one_xcd ? chunk * 64u + (uint32_t)lane : seg_begin + (k * 64u + (uint32_t)lane) * Wx + wx;
-            const uint32_t seg_end_x = one_xcd ? nseg : seg_end;
+    for (uint32_t k = 0;; ++k) {
+        if (seg_begin + k * 64u * Wx + wx < seg_end) {
+            const uint32_t sg = seg_begin + (k * 64u + (uint32_t)lane) * Wx + wx;
             uint4 f = make_uint4(0, 0, 0, 0);
             uint4 *fp = reinterpret_cast<uint4 *>(a.flag_cur + (size_t)sg * 16);      // the map is padded to whole segments
-            if (sg < seg_end_x) f = *fp;
+            if (sg < seg_end) f = *fp;
             const bool any = (f.x | f.y | f.z | f.w) != 0;
             if (__ballot(any)) {
                 if (any) *fp = make_uint4(0, 0, 0, 0);
@@ -1179,7 +1153,7 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     was[j] = 1;
-                    if ((fw[j >> 2] >> (8 * (j & 3))) & 0xffu) was[j] = own_claim<XL>(a, sg * 16u + (uint32_t)j);
+                    if ((fw[j >> 2] >> (8 * (j & 3))) & 0xffu) was[j] = own_claim(a, sg * 16u + (uint32_t)j);
                 }
 #pragma unroll
                 for (int j = 0; j < 16; ++j) enqueue(was[j] == 0, sg * 16u + (uint32_t)j);
@@ -1212,7 +1186,7 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
                 if (wide) res = eval_block<BS, true>(a, r, c, sub, BBME_NEW_MASK);
                 else res = eval_block_lanes<BS, true>(a, r, c, sub, BBME_NEW_MASK, prof);
                 changed = leader && res != prev;
-                if (changed) store_est<XL>(a.est + x, res);
+                if (changed) __hip_atomic_store(a.est + x, res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             evaluated += cnt;
             if (__ballot(changed)) BBME_DRAIN();                       // the stores have completed
@@ -1227,10 +1201,10 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
                 want[d] = changed && rr < a.rows && cc >= 0 && cc < a.cols;
                 xd[d] = want[d] ? (uint32_t)rr * a.cols + cc : 0u;
                 was[d] = 1;
-                if (want[d]) was[d] = own_claim<XL>(a, xd[d]);
+                if (want[d]) was[d] = own_claim(a, xd[d]);
             }
             uint32_t wasx = 0;
-            if (leader) wasx = own_release<XL>(a, x);
+            if (leader) wasx = own_release(a, x);
             BBME_PHASE(prof, 4);                                        // claim dependants + release
             // the newly owned dependants go on the queue: the four ballots first, then the stores, so
             // that the round does not wait on four enqueues in a row
@@ -1259,7 +1233,7 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
             // an input changed while we held x: take it again (unless somebody else just did)
             if (__ballot(leader && wasx >= 2)) {
                 bool again = false;
-                if (leader && wasx >= 2) again = own_claim<XL>(a, x) == 0;
+                if (leader && wasx >= 2) again = own_claim(a, x) == 0;
                 enqueue(again, x);
             }
             if (wasx >= 0x80000000u) a.counters[5] = 1;                // counter close to overflow: report
@@ -1279,7 +1253,7 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
     if (threadIdx.x == 0) s_ticket = atomicAdd(&a.counters[6], 1u);
     __syncthreads();
     if (s_ticket != gridDim.x - 1) return;
-    drain_lists<BS, XL>(a, threadIdx.x, (int)blockDim.x);
+    drain_lists<BS>(a, threadIdx.x, (int)blockDim.x);
 }
 
 // =======================================================================================
