@@ -163,6 +163,19 @@ def test_random_configurations_twice(bbme, oracle, seed):
     c = mf.calcMotionBlockMatching()
     mf.close()
     assert np.array_equal(c, exp), "a one-wave solver changes the field"
+    # the tile-resident relaxation launches before the solver (by default only on grids of >= 100 000 blocks at b <= 4)
+    # forced into every sweep: any number of them must leave the result untouched
+    for steps in ("1", "3"):
+        os.environ["BBME_RELAX_STEPS"] = steps
+        try:
+            mf = bbme.MF(f1, f2, search, blocks, L)
+        finally:
+            del os.environ["BBME_RELAX_STEPS"]
+        for lvl in range(L):
+            mf.set_level_planes(lvl, omf.image(lvl, 1), omf.image(lvl, 2))
+        c = mf.calcMotionBlockMatching()
+        mf.close()
+        assert np.array_equal(c, exp), "%s relaxation steps per sweep change the field" % steps
 
 
 def test_non_convergence_is_an_error(bbme):
@@ -235,6 +248,22 @@ def test_stagewise_parity_with_a_one_wave_solver(bbme, oracle, monkeypatch):
     n1 = rng.integers(0, 256, (160, 224), dtype=np.uint8)
     n2 = rng.integers(0, 256, (160, 224), dtype=np.uint8)
     compare_stagewise(bbme, oracle, n1, n2, [40, 40], [8, 8])
+
+
+def test_stagewise_parity_with_relaxation_steps(bbme, oracle, monkeypatch):
+    """Every intermediate MV grid with two relaxation launches forced into every sweep (k_reg_iter: the tile-resident
+    local fixed point), on content with many changes per sweep and on every block size."""
+    monkeypatch.setenv("BBME_RELAX_STEPS", "2")
+    f1, f2, _ = bbme.synth_pair(328, 200, 5151, max_motion=12)
+    compare_stagewise(bbme, oracle, f1, f2, [48, 48, 48], [16, 16, 16])
+    rng = np.random.default_rng(12)
+    n1 = rng.integers(0, 256, (160, 224), dtype=np.uint8)
+    n2 = rng.integers(0, 256, (160, 224), dtype=np.uint8)
+    compare_stagewise(bbme, oracle, n1, n2, [40, 40], [8, 8])
+    compare_stagewise(bbme, oracle, n1, n2, [12, 12], [4, 4])
+    f1, f2, _ = bbme.synth_pair(512, 512, 5152, max_motion=30)
+    compare_stagewise(bbme, oracle, f1, f2, [64, 64, 64], [32, 32, 32])
+    compare_stagewise(bbme, oracle, f1, f2, [80, 80], [64, 64])
 
 
 def test_noise_frames(bbme, oracle):
