@@ -54,6 +54,8 @@ SIGNATURES = {
     "bbme_flo_write": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_void_p]),
     "bbme_flo_writer_create": (C.c_int, [_P(C.c_void_p)]),
     "bbme_flo_writer_submit": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "bbme_flo_writer_submit_cells": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                               C.c_int, C.c_int]),
     "bbme_flo_writer_wait": (C.c_int, [C.c_void_p]),
     "bbme_flo_writer_destroy": (C.c_int, [C.c_void_p]),
     "bbme_calculate_mse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _P(C.c_double)]),

@@ -4,6 +4,8 @@
 // (rw_flow.cpp:39-200,309-332).  No GPU code here; no dependency on oracle/.
 #include "bbme_internal.hpp"
 
+#include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -15,6 +17,9 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <vector>
+#include <fcntl.h>
+#include <unistd.h>
 
 namespace bbme {
 
@@ -556,7 +561,10 @@ void bbme_free(void *p) { free(p); }
 // same bytes WriteFlowFile would ("PIEH", width, height, rows of interleaved u, v).  The buffer must stay untouched
 // until bbme_flo_writer_wait returns.
 struct bbme_flo_writer {
-    struct Job { std::string name; int width, height; const float *data; size_t pitch_floats; };
+    struct Job {
+        std::string name; int width, height; const float *data; size_t pitch_floats;
+        const int16_t *cells; int cell_pitch, pad_x, pad_y;          // cells != nullptr: expand the 2x2-cell grid while writing
+    };
     std::mutex mu;
     std::condition_variable cv_job, cv_idle;
     std::deque<Job> jobs;
@@ -565,6 +573,62 @@ struct bbme_flo_writer {
     std::string error;
     std::thread worker;
 };
+
+// copy_to_all_pixels (motion_framework.cpp:815-826) + the padding strip of main_class.cpp:63-70 + WriteFlowFile's rows, fused:
+// pixel (x, y) of the file is the (dx, dy) of cell ((y + pad_y) / 2, (x + pad_x) / 2) as two floats.  The file is cut into bands
+// of rows; a few threads expand bands into private buffers and pwrite them at their offsets (one thread fills ~5 GB/s, the
+// 66 MB of a 4K field want more).
+static bool flo_write_cells(const bbme_flo_writer::Job &job)
+{
+    const int fd = open(job.name.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return false;
+    const size_t row_bytes = (size_t)job.width * 8;
+    struct { char tag[4]; int32_t w, h; } head;
+    memcpy(head.tag, bbme::kTagString, 4);
+    head.w = job.width; head.h = job.height;
+    // (measured on the GPU box's host, 66 MB per 4K field: 10 ms to tmpfs, 6 ms to the page cache, whatever the number of
+    // threads -- the kernel's write path is the bound; mapping the file and expanding into the mapping was slower: 14-30 ms)
+    std::atomic<bool> ok(pwrite(fd, &head, 12, 0) == 12);
+    const int band = std::max(2, (int)((1u << 20) / row_bytes) & ~1);             // ~1 MB of output per band
+    const int nbands = (job.height + band - 1) / band;
+    int nthreads = 2;
+    if (const char *e = getenv("BBME_WRITER_THREADS")) nthreads = atoi(e);
+    nthreads = std::max(1, std::min(nthreads, std::min(nbands, 64)));
+    std::atomic<int> next(0);
+    auto work = [&]() {
+        std::vector<float> buf((size_t)band * job.width * 2);
+        for (int b = next.fetch_add(1); b < nbands && ok.load(); b = next.fetch_add(1)) {
+            const int y0 = b * band, y1 = std::min(job.height, y0 + band);
+            for (int y = y0; y < y1; ++y) {
+                float *out = buf.data() + (size_t)(y - y0) * job.width * 2;
+                const int py = y + job.pad_y;
+                if (y > y0 && (py & 1)) {                                          // second row of a cell row: same values
+                    memcpy(out, out - (size_t)job.width * 2, row_bytes);
+                    continue;
+                }
+                const int16_t *crow = job.cells + (size_t)(py >> 1) * job.cell_pitch * 2;
+                for (int x = 0; x < job.width; ++x) {
+                    const int16_t *c = crow + (size_t)((x + job.pad_x) >> 1) * 2;
+                    out[2 * x] = (float)c[0];
+                    out[2 * x + 1] = (float)c[1];
+                }
+            }
+            const size_t bytes = (size_t)(y1 - y0) * row_bytes;
+            const char *src = reinterpret_cast<const char *>(buf.data());
+            size_t done = 0;
+            while (done < bytes) {
+                const ssize_t n = pwrite(fd, src + done, bytes - done, (off_t)(12 + (size_t)y0 * row_bytes + done));
+                if (n <= 0) { ok.store(false); break; }
+                done += (size_t)n;
+            }
+        }
+    };
+    std::vector<std::thread> helpers;
+    for (int i = 1; i < nthreads; ++i) helpers.emplace_back(work);
+    work();
+    for (auto &t : helpers) t.join();
+    return (close(fd) == 0) && ok.load();
+}
 
 static void flo_writer_main(bbme_flo_writer *w)
 {
@@ -577,7 +641,8 @@ static void flo_writer_main(bbme_flo_writer *w)
         w->busy = true;
         lk.unlock();
         bool ok = false;
-        if (FILE *f = fopen(job.name.c_str(), "wb")) {
+        if (job.cells) ok = flo_write_cells(job);
+        else if (FILE *f = fopen(job.name.c_str(), "wb")) {
             ok = fwrite(bbme::kTagString, 1, 4, f) == 4 && fwrite(&job.width, 4, 1, f) == 1 && fwrite(&job.height, 4, 1, f) == 1;
             const size_t row = (size_t)job.width * 2;
             if (job.pitch_floats == row) ok = ok && fwrite(job.data, sizeof(float), row * job.height, f) == row * job.height;
@@ -613,7 +678,27 @@ int bbme_flo_writer_submit(bbme_flo_writer *w, const char *filename, int width, 
     if (strcmp(dot, ".flo") != 0) return bbme::fail(BBME_ERR_IO, "WriteFlowFile: filename should have extension '.flo'");
     {
         std::lock_guard<std::mutex> lk(w->mu);
-        w->jobs.push_back({filename, width, height, data, (size_t)pitch_pixels * 2});
+        w->jobs.push_back({filename, width, height, data, (size_t)pitch_pixels * 2, nullptr, 0, 0, 0});
+    }
+    w->cv_job.notify_one();
+    return BBME_OK;
+}
+
+int bbme_flo_writer_submit_cells(bbme_flo_writer *w, const char *filename, int width, int height, const int16_t *cells,
+                                 int cell_rows, int cell_cols, int pad_x, int pad_y)
+{
+    if (!w || !cells || width < 1 || height < 1 || pad_x < 0 || pad_y < 0 || cell_rows < 1 || cell_cols < 1)
+        return bbme::fail(BBME_ERR_INVALID, "bbme_flo_writer_submit_cells: bad arguments");
+    if (width + pad_x > 2 * cell_cols || height + pad_y > 2 * cell_rows)
+        return bbme::fail(BBME_ERR_INVALID, "bbme_flo_writer_submit_cells: a %dx%d window at (%d, %d) does not fit %dx%d cells of 2x2",
+                          width, height, pad_x, pad_y, cell_cols, cell_rows);
+    if (!filename) return bbme::fail(BBME_ERR_IO, "WriteFlowFile: empty filename");
+    const char *dot = strrchr(filename, '.');
+    if (!dot) return bbme::fail(BBME_ERR_IO, "WriteFlowFile: extension required in filename");
+    if (strcmp(dot, ".flo") != 0) return bbme::fail(BBME_ERR_IO, "WriteFlowFile: filename should have extension '.flo'");
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->jobs.push_back({filename, width, height, nullptr, 0, cells, cell_cols, pad_x, pad_y});
     }
     w->cv_job.notify_one();
     return BBME_OK;

@@ -3,8 +3,9 @@
 //   bbme_seq --gpus N [--levels L] [--block B] [--search S] --out DIR  f0a.pgm f0b.pgm  f1a.pgm f1b.pgm ...
 //
 // Pair p runs on GPU p mod N (one context per GPU, whole pyramid, no exchange: SURVEY.md 8e); after every round of N
-// pairs the compact cell grids are gathered on GPU 0 with one ncclGather (bbme_gather_cells), expanded there to the
-// dense fields and written as DIR/0000.flo, 0001.flo, ... by the asynchronous writer while the next round runs.
+// pairs the compact cell grids are gathered on GPU 0 with one ncclGather (bbme_gather_cells), downloaded in one copy and
+// written as DIR/0000.flo, 0001.flo, ... by the asynchronous writer, which expands them to the dense fields as it
+// writes, while the next round runs.
 // One process drives all N GPUs here (ncclCommInitAll); bbme_gather_cells itself does not care who owns the ranks.
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
@@ -90,17 +91,16 @@ int main(int argc, char **argv)
     }
     int pw = 0, ph = 0, pad_x = 0, pad_y = 0;
     BBME_OKAY(bbme_get_geometry(ctx[0], &pw, &ph, &pad_x, &pad_y));
-    const size_t words = (size_t)(pw / 2) * (ph / 2), field = (size_t)pw * ph * 2;
+    const size_t words = (size_t)(pw / 2) * (ph / 2);
     int32_t *d_recv = nullptr;
-    float *d_flow = nullptr;
     HIP_OK(hipSetDevice(0));
     HIP_OK(hipMalloc(&d_recv, words * gpus * sizeof(int32_t)));
-    HIP_OK(hipMalloc(&d_flow, field * sizeof(float)));
     void *stream0 = nullptr;
     BBME_OKAY(bbme_get_stream(ctx[0], &stream0));
-    // pinned staging for the writer: one buffer per pair of a round, double-buffered over rounds
-    std::vector<float *> host(2 * gpus, nullptr);
-    for (auto &p : host) HIP_OK(hipHostMalloc(&p, field * sizeof(float)));
+    // pinned staging for the writer: the gathered cell grids of a round (1/16 of the dense fields), double-buffered over
+    // rounds; the writer expands them while it writes (bbme_flo_writer_submit_cells)
+    int32_t *host[2] = {nullptr, nullptr};
+    for (auto &p : host) HIP_OK(hipHostMalloc(&p, words * gpus * sizeof(int32_t)));
     bbme_flo_writer *writer = nullptr;
     BBME_OKAY(bbme_flo_writer_create(&writer));
 
@@ -117,17 +117,17 @@ int main(int argc, char **argv)
         for (int r = 0; r < gpus; ++r) BBME_OKAY(bbme_gather_cells(ctx[r], comms[r], 0, d_recv));
         NCCL_OK(ncclGroupEnd());
         if (k >= 2) BBME_OKAY(bbme_flo_writer_wait(writer));  // the staging buffers of round k - 2 are free again
+        int32_t *dst = host[k & 1];
+        HIP_OK(hipMemcpyAsync(dst, d_recv, words * gpus * sizeof(int32_t), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream0)));
+        HIP_OK(hipStreamSynchronize(static_cast<hipStream_t>(stream0)));
         for (int r = 0; r < gpus; ++r) {
             const int p = k * gpus + r;
             if (p >= n_pairs) continue;
-            float *dst = host[(k & 1) * gpus + r];
-            BBME_OKAY(bbme_expand_gathered(ctx[0], d_recv, r, d_flow));
-            HIP_OK(hipMemcpyAsync(dst, d_flow, field * sizeof(float), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream0)));
-            HIP_OK(hipStreamSynchronize(static_cast<hipStream_t>(stream0)));
             char name[32];
             snprintf(name, sizeof name, "/%04d.flo", p);
             const std::string path = std::string(out_dir) + name;
-            BBME_OKAY(bbme_flo_writer_submit(writer, path.c_str(), w, h, dst + 2 * ((size_t)pad_y * pw + pad_x), pw));
+            BBME_OKAY(bbme_flo_writer_submit_cells(writer, path.c_str(), w, h, reinterpret_cast<const int16_t *>(dst + (size_t)r * words),
+                                                   ph / 2, pw / 2, pad_x, pad_y));
         }
     }
     for (int r = 0; r < gpus; ++r) BBME_OKAY(bbme_synchronize(ctx[r]));       // also refuses a field that did not converge
@@ -138,7 +138,7 @@ int main(int argc, char **argv)
 
     bbme_flo_writer_destroy(writer);
     for (auto p : host) (void)hipHostFree(p);
-    (void)hipFree(d_recv); (void)hipFree(d_flow);
+    (void)hipFree(d_recv);
     for (int r = 0; r < gpus; ++r) { bbme_destroy(ctx[r]); ncclCommDestroy(comms[r]); }
     return 0;
 }

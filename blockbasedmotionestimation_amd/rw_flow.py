@@ -98,6 +98,18 @@ class FlowWriter:
         ptr = f.ctypes.data + 8 * (pad_y * f.shape[1] + pad_x)
         _capi.check(_capi.lib().bbme_flo_writer_submit(self._w, os.fsencode(filename), width, height, C.c_void_p(ptr), f.shape[1]))
 
+    def submit_cells(self, cells, filename, pad_x=0, pad_y=0, width=None, height=None):
+        """The same file from the compact result of MF.get_cells (int16 (rows, cols, 2), one (dx, dy) per 2x2 pixels of the
+        padded field): expansion, padding strip and write happen on the worker (bbme_flo_writer_submit_cells)."""
+        c = cells
+        if c.dtype != np.int16 or c.ndim != 3 or c.shape[2] != 2 or not c.flags.c_contiguous:
+            raise _capi.BbmeError(_capi.ERR_INVALID, "FlowWriter.submit_cells: C-contiguous int16 (rows, cols, 2) grid expected")
+        width = 2 * c.shape[1] - pad_x if width is None else width
+        height = 2 * c.shape[0] - pad_y if height is None else height
+        self._keep.append(c)
+        _capi.check(_capi.lib().bbme_flo_writer_submit_cells(self._w, os.fsencode(filename), width, height,
+                                                             C.c_void_p(c.ctypes.data), c.shape[0], c.shape[1], pad_x, pad_y))
+
     def wait(self):
         try:
             _capi.check(_capi.lib().bbme_flo_writer_wait(self._w))

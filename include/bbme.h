@@ -82,6 +82,14 @@ typedef struct bbme_flo_writer bbme_flo_writer;
 int bbme_flo_writer_create(bbme_flo_writer **out);
 int bbme_flo_writer_submit(bbme_flo_writer *w, const char *filename, int width, int height, const float *data,
                            int pitch_pixels);
+/* The same file from the compact result (bbme_get_cells_host: one int16 (dx, dy) pair per 2x2 pixels of the padded level-0
+ * field, cell_rows x cell_cols): copy_to_all_pixels (motion_framework.cpp:815-826), the padding strip (main_class.cpp:63-70)
+ * and WriteFlowFile's rows fused on the worker, which expands and writes bands of rows with a few helper threads
+ * (BBME_WRITER_THREADS, default 2; the kernel's write path is the bound).  Only 1/16 of the dense field crosses PCIe, and nobody holds 8 bytes per pixel in
+ * memory.  Pixel (x, y) of the file = cell ((y + pad_y) / 2, (x + pad_x) / 2).  Byte for byte the file bbme_flo_write makes
+ * of the dense field's window.  `cells` must stay untouched until bbme_flo_writer_wait returns. */
+int bbme_flo_writer_submit_cells(bbme_flo_writer *w, const char *filename, int width, int height, const int16_t *cells,
+                                 int cell_rows, int cell_cols, int pad_x, int pad_y);
 int bbme_flo_writer_wait(bbme_flo_writer *w);
 int bbme_flo_writer_destroy(bbme_flo_writer *w);
 /* Flow::CalculateMSE (rw_flow.cpp:309-332): mean end-point error over known GT pixels. */

@@ -671,6 +671,31 @@ def test_cpp_sequence_driver_over_rccl(bbme, oracle, tmp_path):
         assert np.array_equal(got, expect[p]), "pair %d" % p
 
 
+def test_expand_gathered_grid(bbme):
+    """bbme_expand_gathered (include/bbme_rccl.h): grid `rank` of a gather buffer -> the dense padded field, on the
+    context's stream -- here on a hand-made two-rank buffer whose second grid is this context's own result."""
+    import ctypes as C
+    import torch
+    from blockbasedmotionestimation_amd import build as _build
+    rccl = C.CDLL(_build.RCCL_LIB)
+    rccl.bbme_expand_gathered.restype = C.c_int
+    rccl.bbme_expand_gathered.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    f1, f2, _ = bbme.synth_pair(200, 136, 61, max_motion=6)
+    mf = bbme.MF(f1, f2, [24, 24], [8, 8], 2)
+    want = mf.calcMotionBlockMatching().copy()
+    cells = torch.from_numpy(mf.get_cells().copy()).cuda()
+    words = cells.view(torch.int32).reshape(cells.shape[0], cells.shape[1])
+    recv = torch.stack([torch.zeros_like(words), words]).contiguous()
+    flow = torch.empty((mf.padded_height, mf.padded_width, 2), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for rank, expect in ((1, want), (0, np.zeros_like(want))):
+        assert rccl.bbme_expand_gathered(mf._ctx, recv.data_ptr(), rank, flow.data_ptr()) == 0
+        mf.synchronize()
+        assert np.array_equal(flow.cpu().numpy(), expect)
+    assert rccl.bbme_expand_gathered(mf._ctx, None, 0, flow.data_ptr()) != 0
+    mf.close()
+
+
 def test_jacobi_fast_mode_is_what_it_says(bbme, oracle):
     """the opt-in, NOT bit-exact regulariser mode.  Its definition -- every block of a sweep evaluated
     against the field as the previous sweep left it -- is restated in the oracle (jacobi_regularizer), and the kernels

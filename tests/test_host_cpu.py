@@ -193,6 +193,37 @@ def test_async_flow_writer(bbme, tmp_path):
     w.close()
 
 
+@pytest.mark.parametrize("pads", [(0, 0), (4, 6), (3, 5), (1, 0)])
+@pytest.mark.parametrize("threads", ["1", "3"])
+def test_async_flow_writer_from_cells(bbme, tmp_path, monkeypatch, pads, threads):
+    """bbme_flo_writer_submit_cells: the worker expands the 2x2-cell grid (copy_to_all_pixels, motion_framework.cpp:815-826),
+    strips the padding (main_class.cpp:63-70) and writes -- the file is byte for byte Flow::WriteFlowFile's of the dense
+    field's window, for even and odd paddings, with one and several helper threads, over several bands of rows."""
+    from blockbasedmotionestimation_amd.sequence import cells_to_words, expand_cells_host
+    monkeypatch.setenv("BBME_WRITER_THREADS", threads)
+    rng = np.random.default_rng(5)
+    cells = rng.integers(-300, 300, (151, 160, 2), dtype=np.int16)          # 302 x 320 pixels: 2560-byte rows, several bands
+    dense = expand_cells_host(cells_to_words(cells))
+    px, py = pads
+    wd, ht = 2 * cells.shape[1] - 2 * px, 2 * cells.shape[0] - 2 * py
+    w = bbme.FlowWriter()
+    w.submit_cells(cells, str(tmp_path / "cells.flo"), px, py, wd, ht)
+    w.wait()
+    bbme.Flow().WriteFlowFile(dense[py:py + ht, px:px + wd], str(tmp_path / "dense.flo"))
+    assert (tmp_path / "cells.flo").read_bytes() == (tmp_path / "dense.flo").read_bytes()
+    with pytest.raises(bbme.BbmeError) as e:                                  # window larger than the grid
+        w.submit_cells(cells, str(tmp_path / "x.flo"), 2, 2, 2 * cells.shape[1], 10)
+    assert e.value.status == -1
+    with pytest.raises(bbme.BbmeError) as e:
+        w.submit_cells(cells, str(tmp_path / "x.txt"), px, py, wd, ht)
+    assert e.value.status == -6
+    w.submit_cells(cells, str(tmp_path / "no_such_dir" / "x.flo"), px, py, wd, ht)
+    with pytest.raises(bbme.BbmeError) as e:
+        w.wait()
+    assert e.value.status == -6
+    w.close()
+
+
 def test_flow_errors_raise_instead_of_exit(bbme, tmp_path):
     flow = bbme.Flow()
     good = open(os.path.join(GOLDEN, "flo_ramp_ref.flo"), "rb").read()
