@@ -142,6 +142,8 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-iters", type=int, default=5)
+    ap.add_argument("--no-host-boundary", action="store_true",
+                    help="skip the host_boundary legs (for kernel traces: their pyramids start from freshly uploaded frames)")
     ap.add_argument("--in-flight", type=int, default=8,
                     help="N=1 only: also report the throughput of a sequence with this many independent pairs in flight "
                          "(one context and stream per pair); 0 = skip.  Reported beside `value`, never as `value`")
@@ -257,7 +259,7 @@ def main():
     # the boundary with host buffers (never `value`): frames in (pinned) host memory -> upload (2 x 8.3 MB at 4K), padding +
     # pyramid on the GPU, estimate, download of the dense field (66.8 MB) or of the compact 2x2-cell grid (4.2 MB)
     host_boundary = None
-    if rank == 0 and not use_dist:
+    if rank == 0 and not use_dist and not args.no_host_boundary:
         p1, p2 = torch.from_numpy(f1).pin_memory(), torch.from_numpy(f2).pin_memory()
         reps = 9
 
@@ -385,7 +387,8 @@ def main():
                                     if world > 1 else "single GPU"},
             # contract fields (achieved / peak / unit / frac / traffic) are the HBM figures; what BINDS the kernel is the issue
             # rate of the integer SAD instructions, priced in `binding` against the chip's spec rate
-            "roofline": {"bound": "valu", "kernel": "k_search_fast<%d> (mean of the %d per-level launches)" % (block, levels),
+            "roofline": {"bound": "valu", "kernel": "k_search_fast<%d, W> (mean of the %d per-level launches; W = 2 waves per macroblock on levels of "
+                                   "<= 10000 blocks, else 1)" % (block, levels),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(levels),
                          "algorithmic_bytes_per_launch": round(search_bytes),

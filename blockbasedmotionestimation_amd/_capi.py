@@ -65,6 +65,8 @@ SIGNATURES = {
     "bbme_free": (None, [C.c_void_p]),
     "bbme_spiral_host": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, _P(C.c_int)]),
     "bbme_search_plan_host": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, _P(C.c_int), C.c_void_p, _P(C.c_int), _P(C.c_int)]),
+    "bbme_search_plan_host_waves": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, _P(C.c_int), C.c_void_p, _P(C.c_int),
+                                              _P(C.c_int)]),
     "bbme_create": (C.c_int, [_P(Params), C.c_int, C.c_int, C.c_int, _P(_ctx)]),
     "bbme_destroy": (C.c_int, [_ctx]),
     "bbme_set_stream": (C.c_int, [_ctx, C.c_void_p]),

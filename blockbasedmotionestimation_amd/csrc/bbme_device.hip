@@ -47,6 +47,9 @@ struct Level {
     int rank_pitch = 0;
     uint32_t *tasks = nullptr, *rounds = nullptr;
     int nrounds = 0;
+    uint32_t *tasks2 = nullptr, *rounds2 = nullptr;   // the plan for two waves per macroblock (levels of few blocks)
+    int nrounds2 = 0;
+    bool split_pays = false;                          // the two-wave plan is at least 20 % shorter per wave
     int fast_pitch_dw = 0;
     size_t fast_lds_bytes = 0;
 };
@@ -65,6 +68,8 @@ struct bbme_ctx {
     uint8_t *flags[2] = {nullptr, nullptr};       // dirty flags of the regulariser, one byte per block, all zero between sweeps
     size_t flag_bytes = 0;
     int relax_steps = -1;                         // k_reg_iter launches per sweep; -1 = by grid size (BBME_RELAX_STEPS overrides)
+    bool split_forced = false;                    // threshold given in the environment: split whatever the plans' lengths (tests)
+    int split_blocks = 10000;                     // levels of at most this many macroblocks: two waves per block (BBME_SEARCH_SPLIT_BLOCKS)
     int round_cap = 0;                            // > 0: test knob, the regulariser's waves give up after this many rounds
     uint32_t *own = nullptr;                      // ownership counters of the solver, one word per block
     uint32_t own_pitch = 0;                       // transposed layout: 32 residue classes of own_pitch words
@@ -186,6 +191,16 @@ int launch_search_fast(bbme_ctx *c, int level, int mode, hipStream_t stream, siz
     const int grid = c->xcd_remap ? ((nblocks + 7) / 8) * 8 : nblocks;
     const size_t lds = std::max(L.fast_lds_bytes, lds_floor);
     a.fix_count = L.fix_count;
+    // a level with fewer macroblocks than the chip has SIMDs: one wave per block leaves most SIMDs idle and every busy one
+    // with a single wave, so the launch lasts as long as one block does -- two waves share each block then
+    if (mode == kSearchPlain && L.tasks2 && nblocks <= c->split_blocks && (L.split_pays || c->split_forced)) {
+        a.tasks = L.tasks2; a.rounds = L.rounds2; a.nrounds = L.nrounds2;
+        if (L.block == 16) hipLaunchKernelGGL((k_search_fast<16, 2>), dim3(grid), dim3(128), lds, stream, a);
+        else if (L.block == 32) hipLaunchKernelGGL((k_search_fast<32, 2>), dim3(grid), dim3(128), lds, stream, a);
+        else hipLaunchKernelGGL((k_search_fast<8, 2>), dim3(grid), dim3(128), lds, stream, a);
+        HIP_TRY(hipGetLastError());
+        return BBME_OK;
+    }
     if (mode == kSearchFixup && a.coarse) {
         // list the blocks whose prediction changed, then search those (k_fixup_list, k_search_list)
         a.mode = kSearchPlain;
@@ -198,11 +213,11 @@ int launch_search_fast(bbme_ctx *c, int level, int mode, hipStream_t stream, siz
         return BBME_OK;
     }
     if (L.block == 16)
-        hipLaunchKernelGGL(k_search_fast<16>, dim3(grid), dim3(64), lds, stream, a);
+        hipLaunchKernelGGL((k_search_fast<16, 1>), dim3(grid), dim3(64), lds, stream, a);
     else if (L.block == 32)
-        hipLaunchKernelGGL(k_search_fast<32>, dim3(grid), dim3(64), lds, stream, a);
+        hipLaunchKernelGGL((k_search_fast<32, 1>), dim3(grid), dim3(64), lds, stream, a);
     else
-        hipLaunchKernelGGL(k_search_fast<8>, dim3(grid), dim3(64), lds, stream, a);
+        hipLaunchKernelGGL((k_search_fast<8, 1>), dim3(grid), dim3(64), lds, stream, a);
     HIP_TRY(hipGetLastError());
     return BBME_OK;
 }
@@ -473,6 +488,7 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
     if (const char *e = getenv("BBME_RELAX_STEPS")) c->relax_steps = std::max(0, std::min(64, atoi(e)));
     if (const char *e = getenv("BBME_SOLVE_WAVES")) { const int v = atoi(e); c->solve_waves = v <= 1 ? 1 : (v == 2 ? 2 : 4); }
     if (const char *e = getenv("BBME_TEST_ROUND_CAP")) c->round_cap = std::max(0, atoi(e));
+    if (const char *e = getenv("BBME_SEARCH_SPLIT_BLOCKS")) { c->split_blocks = std::max(0, atoi(e)); c->split_forced = true; }
     if (const char *e = getenv("BBME_NO_GRAPH")) c->use_graph = atoi(e) == 0;
     if (const char *e = getenv("BBME_SPECULATE")) c->speculate = atoi(e) != 0;
     {
@@ -538,6 +554,19 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
                 (err = hipMemcpy(L.tasks, plan.tasks.data(), plan.tasks.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
                 (err = hipMemcpy(L.rounds, plan.rounds.data(), plan.rounds.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
                 return cleanup_fail(bbme::fail(BBME_ERR_HIP, "allocating search plan of level %d: %s", l, hipGetErrorString(err)));
+            // shorter strips, so that the 128 lanes of two waves have a full round of them
+            SearchPlan plan2 = plan_search(L.range, L.block, 8, 128);
+            L.nrounds2 = (int)plan2.rounds.size();
+            // a round of strips of S rows walks S + B - 1 window rows: the split only pays where it shortens a wave's walk
+            // (+-32 at B <= 16: 0.6x; +-16: the square is too small to fill 128 lanes with tall strips, 0.94-1.0x -- measured slower)
+            auto walk = [&](const SearchPlan &p) { int w = 0; for (uint32_t S : p.rounds) w += (int)S + L.block - 1; return w; };
+            L.split_pays = 5 * walk(plan2) <= 4 * walk(plan);
+            if (plan2.pitch_dw != plan.pitch_dw) return cleanup_fail(bbme::fail(BBME_ERR_STATE, "search plans disagree on the window pitch"));
+            if ((err = hipMalloc(&L.tasks2, plan2.tasks.size() * 4)) != hipSuccess ||
+                (err = hipMalloc(&L.rounds2, plan2.rounds.size() * 4)) != hipSuccess ||
+                (err = hipMemcpy(L.tasks2, plan2.tasks.data(), plan2.tasks.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+                (err = hipMemcpy(L.rounds2, plan2.rounds.data(), plan2.rounds.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
+                return cleanup_fail(bbme::fail(BBME_ERR_HIP, "allocating search plan of level %d: %s", l, hipGetErrorString(err)));
         }
     }
     // pitch = 33 (mod 64) words: consecutive blocks land 132 bytes (mod 256) apart
@@ -575,7 +604,7 @@ int bbme_destroy(bbme_ctx *c)
         (void)hipFree(L.small[0]); (void)hipFree(L.small[1]); (void)hipFree(L.pred);
         (void)hipFree(L.fix_list); (void)hipFree(L.fix_count);
         (void)hipFree(L.big[0]); (void)hipFree(L.big[1]); (void)hipFree(L.spiral);
-        (void)hipFree(L.rank_of); (void)hipFree(L.tasks); (void)hipFree(L.rounds);
+        (void)hipFree(L.rank_of); (void)hipFree(L.tasks); (void)hipFree(L.rounds); (void)hipFree(L.tasks2); (void)hipFree(L.rounds2);
     }
     (void)hipFree(c->flow);
     (void)hipFree(c->epe_scratch);

@@ -229,7 +229,7 @@ SpiralTable build_spiral(int search_size, int block_size)
 // full: take the tallest strip height that still has 64 strips available; what is left (< 64
 // single rows) goes into one last round of height 1.
 // ---------------------------------------------------------------------------------------
-SearchPlan plan_search(int range, int block_size, int max_strip)
+SearchPlan plan_search(int range, int block_size, int max_strip, int lanes)
 {
     SearchPlan p;
     const int n = 2 * range + 1;
@@ -250,20 +250,20 @@ SearchPlan plan_search(int range, int block_size, int max_strip)
                     more = true;
                 }
         }
-        t.resize(64, 0xffffffffu);
+        t.resize((size_t)((t.size() + lanes - 1) / lanes * lanes), 0xffffffffu);   // whole rounds of `lanes` tasks
         p.tasks.insert(p.tasks.end(), t.begin(), t.end());
     };
     for (int s = max_strip; s >= 1; s >>= 1) {
         for (;;) {
             int avail = 0;
             for (int g = 0; g < p.groups; ++g) avail += (n - next[g]) / s;
-            if (avail >= 64) emit_round(s, 64);
+            if (avail >= lanes) emit_round(s, lanes);
             else break;
         }
     }
     int left = 0;
     for (int g = 0; g < p.groups; ++g) left += n - next[g];
-    if (left > 0) emit_round(1, left);
+    while (left > 0) { emit_round(1, std::min(left, lanes)); left -= std::min(left, lanes); }
     return p;
 }
 
@@ -537,20 +537,27 @@ int bbme_spiral_host(int search_size, int block_size, int16_t *dx, int16_t *dy, 
     return BBME_OK;
 }
 
-int bbme_search_plan_host(int range, int block_size, uint32_t *rounds, int rounds_capacity, int *nrounds,
-                          uint32_t *tasks, int *groups, int *pitch_dw)
+int bbme_search_plan_host_waves(int range, int block_size, int waves, uint32_t *rounds, int rounds_capacity, int *nrounds,
+                                uint32_t *tasks, int *groups, int *pitch_dw)
 {
-    if (!nrounds || range < 0 || range > 63 || (block_size != 8 && block_size != 16 && block_size != 32))
+    if (!nrounds || range < 0 || range > 63 || (block_size != 8 && block_size != 16 && block_size != 32) || waves < 1 || waves > 2)
         return bbme::fail(BBME_ERR_INVALID, "bbme_search_plan_host: bad arguments");
-    const bbme::SearchPlan p = bbme::plan_search(range, block_size, block_size == 32 ? 8 : 16);
+    const int lanes = 64 * waves;
+    const bbme::SearchPlan p = bbme::plan_search(range, block_size, waves == 2 || block_size == 32 ? 8 : 16, lanes);
     *nrounds = (int)p.rounds.size();
     if (groups) *groups = p.groups;
     if (pitch_dw) *pitch_dw = p.pitch_dw;
     for (int i = 0; i < *nrounds && i < rounds_capacity; ++i) {
         if (rounds) rounds[i] = p.rounds[i];
-        if (tasks) memcpy(tasks + (size_t)i * 64, p.tasks.data() + (size_t)i * 64, 64 * sizeof(uint32_t));
+        if (tasks) memcpy(tasks + (size_t)i * lanes, p.tasks.data() + (size_t)i * lanes, lanes * sizeof(uint32_t));
     }
     return BBME_OK;
+}
+
+int bbme_search_plan_host(int range, int block_size, uint32_t *rounds, int rounds_capacity, int *nrounds,
+                          uint32_t *tasks, int *groups, int *pitch_dw)
+{
+    return bbme_search_plan_host_waves(range, block_size, 1, rounds, rounds_capacity, nrounds, tasks, groups, pitch_dw);
 }
 
 void bbme_free(void *p) { free(p); }

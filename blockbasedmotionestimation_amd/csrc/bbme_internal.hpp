@@ -43,7 +43,8 @@ struct SearchPlan {
     int groups = 0;                        // column groups = ceil((2R+1) / 4)
     int pitch_dw = 0;                      // LDS window pitch in dwords (odd, >= groups + B/4)
 };
-SearchPlan plan_search(int range, int block_size, int max_strip);
+// lanes = 64 x the waves that share one macroblock: a round is `lanes` tasks, wave w takes tasks [64 w, 64 w + 64)
+SearchPlan plan_search(int range, int block_size, int max_strip, int lanes = 64);
 
 // ---- Flow (rw_flow.cpp) ---------------------------------------------------------------
 int flo_read(const char *filename, int *width, int *height, float **data);

@@ -340,18 +340,22 @@ __device__ __forceinline__ uint32_t search_strip(const uint32_t *win, int P, con
 }
 
 // The search of macroblock `bid` from the coarse MV `m` (one wave; smem = the workgroup's dynamic LDS).
-template <int B>
+// W waves share the macroblock (W = 2 on levels too small to give every SIMD two waves): they stage the window together,
+// each keeps the block in its own SGPRs, wave w takes tasks [64 w, 64 w + 64) of every round, and the W minima meet in LDS.
+template <int B, int W = 1>
 __device__ __forceinline__ void search_block_fast(const FastSearchArgs &a, uint32_t bid, mv_t m, uint32_t *smem)
 {
     constexpr int BW = B / 4;
+    constexpr int T = 64 * W;                                // threads staging the window
     const int lane = threadIdx.x & 63;
+    const int tid = W == 1 ? lane : (int)threadIdx.x;
     const int bc = (int)(bid % (uint32_t)a.cols), br = (int)(bid / (uint32_t)a.cols);
     const int i = br * B, j = bc * B;
     const int u = 2 * mv_x(m), v = 2 * mv_y(m);             // copyMVs doubles the coarse MV (:836)
     const int px = j + u, py = i + v;                       // :233-234
     mv_t *dst = a.out + (size_t)br * a.cols + bc;
-    if (px < 0 || py < 0 || px + B > a.width || py + B > a.height) {    // :304-310
-        if (lane == 0) *dst = 0;
+    if (px < 0 || py < 0 || px + B > a.width || py + B > a.height) {    // :304-310 (workgroup-uniform)
+        if (tid == 0) *dst = 0;
         return;
     }
     const int R = a.range, P = a.pitch_dw;
@@ -365,8 +369,8 @@ __device__ __forceinline__ void search_block_fast(const FastSearchArgs &a, uint3
     const int wbytes = 4 * P;
     if (wx0 >= 0 && wx0 + wbytes <= a.width && wy0 >= 0 && wy0 + wrows <= a.height) {
         const int nch = (P + 3) >> 2;                        // chunks per row, the last one partial
-        const int rpp = 64 / nch;                            // rows per pass
-        const int rr = lane / nch, ch = lane - rr * nch;
+        const int rpp = T / nch;                             // rows per pass
+        const int rr = tid / nch, ch = tid - rr * nch;
         const int nd = min(4, P - 4 * ch);                   // dwords of this lane's chunk that belong to the row
         const uint8_t *src = a.image2 + (size_t)(wy0 + rr) * a.width + wx0 + 16 * ch;
         uint32_t *dstw = smem + rr * P + 4 * ch;
@@ -390,8 +394,8 @@ __device__ __forceinline__ void search_block_fast(const FastSearchArgs &a, uint3
         }
     } else {
         // near the image border: lane (rr, k) produces dword k of rows rr, rr + RPI, ... re-aligned by sh0 bytes, zeros outside
-        const int rpi = 64 / P;                              // rows per pass
-        const int rr = lane / P, k = lane - rr * P;
+        const int rpi = T / P;                               // rows per pass
+        const int rr = tid / P, k = tid - rr * P;
         if (rr < rpi) {
             const int x = ax0 + 4 * k;
             const bool x_lo_ok = x >= 0 && x + 4 <= a.width;
@@ -426,7 +430,7 @@ __device__ __forceinline__ void search_block_fast(const FastSearchArgs &a, uint3
             for (int q = 0; q < BW; ++q) cur.sg[r][q] = c1[q];
         }
     } else {
-        for (int idx = lane; idx < B * BW; idx += 64) {
+        for (int idx = tid; idx < B * BW; idx += T) {
             const int r = idx / BW, q = idx - r * BW;
             smem[wrows * P + idx] = *reinterpret_cast<const uint32_t *>(a.image1 + (size_t)(i + r) * a.width + j + 4 * q);
         }
@@ -441,7 +445,7 @@ __device__ __forceinline__ void search_block_fast(const FastSearchArgs &a, uint3
     uint32_t best = 0xffffffffu;
     for (int rd = 0; rd < a.nrounds; ++rd) {
         const uint32_t S = a.rounds[rd];
-        const uint32_t task = a.tasks[rd * 64 + lane];
+        const uint32_t task = a.tasks[rd * T + tid];
         switch (S) {
         case 16: if constexpr (B <= 16) { best = search_strip<B, 16>(smem, P, cur, task, a, best, border, xlo, xhi, ylo, yhi); } break;
         case 8:  best = search_strip<B, 8>(smem, P, cur, task, a, best, border, xlo, xhi, ylo, yhi); break;
@@ -452,14 +456,21 @@ __device__ __forceinline__ void search_block_fast(const FastSearchArgs &a, uint3
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o));
-    if (lane == 0) {
+    if constexpr (W > 1) {
+        __shared__ uint32_t wave_best[W];
+        if (lane == 0) wave_best[threadIdx.x >> 6] = best;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < W; ++w) best = min(best, wave_best[w]);
+    }
+    if (tid == 0) {
         const uint32_t sp = a.spiral[best & (B > 16 ? 0x3fffu : 0xffffu)];
         *dst = mv_pack(u + (int)(int16_t)(sp & 0xffffu), v + (int)(int16_t)(sp >> 16));   // :238-239
     }
 }
 
-template <int B>
-__global__ __launch_bounds__(64) void k_search_fast(FastSearchArgs a)
+template <int B, int W>
+__global__ __launch_bounds__(64 * W) void k_search_fast(FastSearchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // Workgroups are dealt round-robin over the 8 XCDs, each with a private L2.  Give every XCD a
@@ -471,7 +482,7 @@ __global__ __launch_bounds__(64) void k_search_fast(FastSearchArgs a)
     if (bid >= (uint32_t)a.nblocks) return;
     mv_t m;                                                 // copyMVs (:828-843)
     if (!search_prediction(a, (int)(bid / (uint32_t)a.cols) * B, (int)(bid % (uint32_t)a.cols) * B, bid, m)) return;
-    search_block_fast<B>(a, bid, m, smem);
+    search_block_fast<B, W>(a, bid, m, smem);
 }
 
 // The fix-up behind a speculative search, in two launches (one workgroup per macroblock that mostly returns at once costs

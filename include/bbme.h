@@ -114,6 +114,10 @@ void bbme_free(void *p);
 int bbme_spiral_host(int search_size, int block_size, int16_t *dx, int16_t *dy, int capacity, int *count);
 int bbme_search_plan_host(int range, int block_size, uint32_t *rounds, int rounds_capacity, int *nrounds,
                           uint32_t *tasks /* rounds_capacity * 64 */, int *groups, int *pitch_dw);
+/* the split used when `waves` (1 or 2) waves share a macroblock (levels with fewer blocks than the chip has SIMDs):
+ * 64 * waves tasks per round, wave w takes tasks [64 w, 64 w + 64) of each */
+int bbme_search_plan_host_waves(int range, int block_size, int waves, uint32_t *rounds, int rounds_capacity, int *nrounds,
+                                uint32_t *tasks /* rounds_capacity * 64 * waves */, int *groups, int *pitch_dw);
 
 /* ---- context: one per GPU stream (replaces an MF object) ---------------------------- */
 

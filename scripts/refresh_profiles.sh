@@ -23,8 +23,8 @@ echo "pmc write done"
 find $OUT -name "*kernel_trace.csv" -size +20M -delete
 # traces for profiles/rNN_sweep_table.txt (speculation off: the sweeps as they are on their own) and rNN_speculation_timeline.txt
 export BBME_SPECULATE=0
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_plain -- python3 $REPO/bench.py --steps 8 --warmup 2 --no-cpu-baseline --profile-iters 1 --in-flight 0 > $OUT/trace_plain.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_plain -- python3 $REPO/bench.py --steps 8 --warmup 2 --no-cpu-baseline --profile-iters 1 --in-flight 0 --no-host-boundary > $OUT/trace_plain.log 2>&1 || exit 1
 unset BBME_SPECULATE
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_spec -- python3 $REPO/bench.py --steps 8 --warmup 2 --no-cpu-baseline --profile-iters 1 --in-flight 0 > $OUT/trace_spec.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_spec -- python3 $REPO/bench.py --steps 8 --warmup 2 --no-cpu-baseline --profile-iters 1 --in-flight 0 --no-host-boundary > $OUT/trace_spec.log 2>&1 || exit 1
 echo "traces done"
 find $OUT -name "*kernel_trace.csv" -size +20M -delete

@@ -7,12 +7,14 @@ pyramids of the timed loop (the asynchronous solver's schedule differs from repl
 
 One line per level: the search, then per sweep  pass1+[relaxation]+solve."""
 import csv, glob, sys
-f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
+import os
+f = max(glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True), key=os.path.getmtime)   # the newest trace
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'k_expand' in r['Kernel_Name']]
 # pyramids between consecutive k_expand launches; keep those with the most common kernel count (the graph replays)
 spans = [(idx[i] + 1, idx[i + 1] + 1) for i in range(len(idx) - 1)]
 from collections import Counter
+spans = [s for s in spans if any('k_reg_solve' in rows[k]['Kernel_Name'] for k in range(*s))]   # not the Jacobi-mode pyramids
 common = Counter(b - a for a, b in spans).most_common(1)[0][0]
 spans = [s for s in spans if s[1] - s[0] == common][1:]          # drop the first (warm-up)
 n = len(spans)

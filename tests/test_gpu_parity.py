@@ -153,11 +153,13 @@ def test_random_configurations_twice(bbme, oracle, seed):
     # the split of the work between the tile kernel's local fixed point and the solver, and the number of solver
     # waves, are pure scheduling: a solver of one workgroup of one wave must leave the same field
     import os
-    os.environ["BBME_SOLVE_WGS"], os.environ["BBME_SOLVE_WAVES"] = "1", "1"
+    # (so is the number of waves that share a macroblock in the search: two by default on levels of <= 1024 blocks --
+    # never here, and on every level in the relaxation runs below)
+    os.environ["BBME_SOLVE_WGS"], os.environ["BBME_SOLVE_WAVES"], os.environ["BBME_SEARCH_SPLIT_BLOCKS"] = "1", "1", "0"
     try:
         mf = bbme.MF(f1, f2, search, blocks, L)
     finally:
-        del os.environ["BBME_SOLVE_WGS"], os.environ["BBME_SOLVE_WAVES"]
+        del os.environ["BBME_SOLVE_WGS"], os.environ["BBME_SOLVE_WAVES"], os.environ["BBME_SEARCH_SPLIT_BLOCKS"]
     for lvl in range(L):
         mf.set_level_planes(lvl, omf.image(lvl, 1), omf.image(lvl, 2))
     c = mf.calcMotionBlockMatching()
@@ -166,11 +168,11 @@ def test_random_configurations_twice(bbme, oracle, seed):
     # the tile-resident relaxation launches before the solver (by default only on grids of >= 100 000 blocks at b <= 4)
     # forced into every sweep: any number of them must leave the result untouched
     for steps in ("1", "3"):
-        os.environ["BBME_RELAX_STEPS"] = steps
+        os.environ["BBME_RELAX_STEPS"], os.environ["BBME_SEARCH_SPLIT_BLOCKS"] = steps, "100000000"
         try:
             mf = bbme.MF(f1, f2, search, blocks, L)
         finally:
-            del os.environ["BBME_RELAX_STEPS"]
+            del os.environ["BBME_RELAX_STEPS"], os.environ["BBME_SEARCH_SPLIT_BLOCKS"]
         for lvl in range(L):
             mf.set_level_planes(lvl, omf.image(lvl, 1), omf.image(lvl, 2))
         c = mf.calcMotionBlockMatching()

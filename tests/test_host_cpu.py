@@ -297,25 +297,32 @@ def test_spiral_table_equals_reference_loop_walk(bbme, oracle, search, block):
     assert np.array_equal(dx, odx) and np.array_equal(dy, ody)
 
 
+@pytest.mark.parametrize("waves", [1, 2])
 @pytest.mark.parametrize("block", [8, 16, 32])
 @pytest.mark.parametrize("rng", [0, 1, 2, 3, 7, 8, 15, 16, 17, 31, 32, 33, 45, 63])
-def test_search_plan_covers_every_candidate_once(bbme, rng, block):
+def test_search_plan_covers_every_candidate_once(bbme, rng, block, waves):
     """k_search_fast's work split: every (column group, candidate row) in exactly one strip, strips of a
-    round all of the round's height, at most 64 per round, rounds full except possibly the last."""
+    round all of the round's height, at most 64 per wave and round, rounds full except possibly the last -- for one wave
+    per macroblock and for the two waves that share a block on levels of few blocks."""
     from blockbasedmotionestimation_amd import _capi
     cap = 256
+    lanes = 64 * waves
     rounds = np.zeros(cap, np.uint32)
-    tasks = np.zeros((cap, 64), np.uint32)
+    tasks = np.zeros((cap, lanes), np.uint32)
     nr, groups, pitch = C.c_int(), C.c_int(), C.c_int()
-    _capi.check(_capi.lib().bbme_search_plan_host(rng, block, rounds.ctypes.data, cap, C.byref(nr), tasks.ctypes.data,
-                                                  C.byref(groups), C.byref(pitch)))
+    _capi.check(_capi.lib().bbme_search_plan_host_waves(rng, block, waves, rounds.ctypes.data, cap, C.byref(nr), tasks.ctypes.data,
+                                                        C.byref(groups), C.byref(pitch)))
+    if waves == 1:                               # the one-wave entry point is the same plan
+        r1, t1, n1 = np.zeros(cap, np.uint32), np.zeros((cap, 64), np.uint32), C.c_int()
+        _capi.check(_capi.lib().bbme_search_plan_host(rng, block, r1.ctypes.data, cap, C.byref(n1), t1.ctypes.data, None, None))
+        assert n1.value == nr.value and np.array_equal(r1, rounds) and np.array_equal(t1, tasks)
     n = 2 * rng + 1
     assert groups.value == (n + 3) // 4 and 1 <= nr.value <= cap
     assert pitch.value % 2 == 1 and pitch.value >= groups.value + block // 4
     covered = np.zeros((groups.value, n), np.int32)
     for r in range(nr.value):
         s = int(rounds[r])
-        assert s in ((8, 4, 2, 1) if block == 32 else (16, 8, 4, 2, 1))
+        assert s in ((8, 4, 2, 1) if block == 32 or waves == 2 else (16, 8, 4, 2, 1))
         busy = 0
         for t in tasks[r]:
             if t == 0xFFFFFFFF:
@@ -324,10 +331,10 @@ def test_search_plan_covers_every_candidate_once(bbme, rng, block):
             g, dy0 = int(t & 0xFF), int((t >> 8) & 0xFF)
             assert g < groups.value and dy0 + s <= n
             covered[g, dy0:dy0 + s] += 1
-        assert 1 <= busy <= 64
+        assert 1 <= busy <= lanes
         if r < nr.value - 1:
-            assert busy == 64 or s == 1
+            assert busy == lanes or s == 1
     assert np.all(covered == 1)
-    # a round costs its strip height; the plan should stay close to the ideal n * groups / 64
+    # a round costs its strip height; the plan should stay close to the ideal n * groups / lanes
     cost = int(sum(int(rounds[r]) for r in range(nr.value)))
-    assert cost <= -(-n * groups.value // 64) + 2
+    assert cost <= -(-n * groups.value // lanes) + 2
