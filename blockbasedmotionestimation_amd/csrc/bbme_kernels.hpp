@@ -846,6 +846,10 @@ __device__ __forceinline__ mv_t eval_block_lanes(const RegArgs &a, int r, int c,
     const LaneCand lc = lanes_candidate(a, r, c, k16, use_new);
     const mv_t mv = load_est<COHERENT>(lc.src);
     BBME_PHASE(prof, 0);                                      // queue pop + address arithmetic + gather trip
+    // every block of the round has nine equal candidates (behind a flood that has passed): equal SADs, equal smoothness, the
+    // first one -- the block's own MV -- stays (:648-660), as in eval_block; no image row is touched
+    const mv_t own = dpp_row<0x150>(mv);
+    if (!__ballot(lc.present && mv != own)) return own;
     return lanes_score<BS>(a, r, c, k16, lc.present, mv, prof);
 }
 
@@ -1202,6 +1206,29 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
             evaluated += cnt;
             if (__ballot(changed)) BBME_DRAIN();                       // the stores have completed
             BBME_PHASE(prof, 3);                                        // store + drain
+            if (!wide) {
+                // chain form: lanes 0..3 of a block's group claim one dependant each (R, DR, D, DL) -- one atomic instruction,
+                // one ballot and one queue write per round instead of four of each, on a path where a lone wave pays
+                // about five cycles for every instruction; the release goes out first, in the same trip
+                uint32_t wasx = 0;
+                if (leader) wasx = own_release(a, x);
+                const bool g_changed = dpp_row<0x150>((uint32_t)changed) != 0;
+                const int tr = r + (sub != 0), tc = c + (sub < 2 ? 1 : 2 - sub);      // (0,+1) (+1,+1) (+1,0) (+1,-1)
+                const bool want = g_changed && sub < 4 && tr < a.rows && tc >= 0 && tc < a.cols;
+                const uint32_t tx = (uint32_t)tr * a.cols + tc;
+                uint32_t was = 1;
+                if (want) was = own_claim(a, tx);
+                BBME_PHASE(prof, 4);                                    // claim dependants + release
+                enqueue(want && was == 0, tx);
+                if (__ballot(leader && wasx >= 2)) {                    // an input changed while we held x: take it again
+                    bool again = false;
+                    if (leader && wasx >= 2) again = own_claim(a, x) == 0;
+                    enqueue(again, x);
+                }
+                if (wasx >= 0x80000000u) a.counters[5] = 1;            // counter close to overflow: report
+                BBME_PHASE(prof, 5);                                    // enqueue + re-claim
+                continue;
+            }
             // one trip for all five atomics: claim the dependants R, DR, D, DL and release x
             const int dr[4] = {0, 1, 1, 1}, dc[4] = {1, 1, 0, -1};
             uint32_t xd[4], was[4];
