@@ -758,6 +758,37 @@ struct LaneCand {
     const mv_t *src;            // where the candidate's MV lives (est for the already-updated inputs, else old_grid)
     bool present;               // k16 < 9 and the neighbour exists
 };
+// The part of lanes_candidate that depends on the lane only (a chain walker computes it once, not every round): the
+// neighbour's offset, and where its MV lives -- `est` for the inputs a raster sweep has already updated, else `old_grid`.
+struct LaneGeom {
+    const mv_t *base;
+    int drow, dcol, pitch, shift;
+    bool cand;                  // k16 < 9
+};
+__device__ __forceinline__ LaneGeom lanes_geometry(const RegArgs &a, int k16, uint32_t use_new)
+{
+    constexpr uint32_t kRowCode = 1u | 1u << 2 | 1u << 4 | 2u << 6 | 0u << 8 | 0u << 10 | 0u << 12 | 2u << 14 | 2u << 16;
+    constexpr uint32_t kColCode = 1u | 0u << 2 | 2u << 4 | 2u << 6 | 0u << 8 | 2u << 10 | 1u << 12 | 1u << 14 | 0u << 16;
+    const int k = k16 < 9 ? k16 : 0;
+    LaneGeom lg;
+    lg.cand = k16 < 9;
+    lg.drow = (int)((kRowCode >> (2 * k)) & 3u) - 1;
+    lg.dcol = (int)((kColCode >> (2 * k)) & 3u) - 1;
+    const bool is_new = (use_new >> k) & 1u;
+    lg.base = is_new ? a.est : a.old_grid;
+    lg.pitch = is_new ? a.cols : a.old_cols;
+    lg.shift = is_new ? 0 : a.old_shift;
+    return lg;
+}
+__device__ __forceinline__ LaneCand lanes_candidate(const RegArgs &a, const LaneGeom &lg, int r, int c)
+{
+    const int rr = r + lg.drow, cc = c + lg.dcol;
+    LaneCand lc;
+    lc.present = lg.cand && (uint32_t)rr < (uint32_t)a.rows && (uint32_t)cc < (uint32_t)a.cols;
+    const int rs = min(max(rr, 0), a.rows - 1), cs = min(max(cc, 0), a.cols - 1);
+    lc.src = lg.base + (size_t)((rs >> lg.shift) * lg.pitch + (cs >> lg.shift));
+    return lc;
+}
 __device__ __forceinline__ LaneCand lanes_candidate(const RegArgs &a, int r, int c, int k16, uint32_t use_new)
 {
     // (drow + 1) and (dcol + 1) of candidate k, two bits each, order C,L,R,DR,UL,UR,U,D,DL (:441-449)
@@ -841,9 +872,9 @@ __device__ __forceinline__ mv_t lanes_score(const RegArgs &a, int r, int c, int 
 
 template <int BS, bool COHERENT>
 __device__ __forceinline__ mv_t eval_block_lanes(const RegArgs &a, int r, int c, int k16, uint32_t use_new,
-                                                 PhaseProf *prof = nullptr)
+                                                 PhaseProf *prof = nullptr, const LaneGeom *lg = nullptr)
 {
-    const LaneCand lc = lanes_candidate(a, r, c, k16, use_new);
+    const LaneCand lc = lg ? lanes_candidate(a, *lg, r, c) : lanes_candidate(a, r, c, k16, use_new);
     const mv_t mv = load_est<COHERENT>(lc.src);
     BBME_PHASE(prof, 0);                                      // queue pop + address arithmetic + gather trip
     // every block of the round has nine equal candidates (behind a flood that has passed): equal SADs, equal smoothness, the
@@ -1153,6 +1184,8 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
         }
     };
 
+    const LaneGeom lgeom = lanes_geometry(a, lane & 15, BBME_NEW_MASK);      // chain form: lane k of a group = candidate k
+
     for (uint32_t k = 0;; ++k) {
         if (seg_begin + k * 64u * Wx + wx < seg_end) {
             const uint32_t sg = seg_begin + (k * 64u + (uint32_t)lane) * Wx + wx;
@@ -1199,7 +1232,7 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
                 if (leader) prev = load_est<true>(a.est + x);          // issued with the candidate loads
                 mv_t res;
                 if (wide) res = eval_block<BS, true>(a, r, c, sub, BBME_NEW_MASK);
-                else res = eval_block_lanes<BS, true>(a, r, c, sub, BBME_NEW_MASK, prof);
+                else res = eval_block_lanes<BS, true>(a, r, c, sub, BBME_NEW_MASK, prof, &lgeom);
                 changed = leader && res != prev;
                 if (changed) __hip_atomic_store(a.est + x, res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
