@@ -839,33 +839,46 @@ __device__ __forceinline__ mv_t lanes_score(const RegArgs &a, int r, int c, int 
     // one DPP row of 16 lanes: candidate m reaches every lane by row_newbcast (a VALU move, no LDS trip)
     const int lane = (int)(threadIdx.x & 63u);
     const int base = lane & ~15;
-    const uint32_t pmask = (uint32_t)(__ballot(present) >> base) & 0x1ffu;
+    const unsigned long long pball = __ballot(present);
     const uint32_t mine = mv ^ 0x80008000u;
     uint32_t smooth = 0;
+    // (lanes 9..15 of a group are never present: a group away from the grid's border shows 0x01ff in its 16 bits)
+    const unsigned long long aball = __ballot(true);          // the active groups, 16 lanes each
+    if (pball == (aball & 0x01ff01ff01ff01ffull)) {
+        // no block of the round touches the border of the grid -- nearly always: nine unconditional terms
+#define BBME_SMOOTH_TERM(m) smooth = __builtin_amdgcn_sad_u16(dpp_row<0x150 + (m)>(mine), mine, smooth);
+        BBME_SMOOTH_TERM(0) BBME_SMOOTH_TERM(1) BBME_SMOOTH_TERM(2) BBME_SMOOTH_TERM(3) BBME_SMOOTH_TERM(4)
+        BBME_SMOOTH_TERM(5) BBME_SMOOTH_TERM(6) BBME_SMOOTH_TERM(7) BBME_SMOOTH_TERM(8)
+#undef BBME_SMOOTH_TERM
+    } else {
+        const uint32_t pmask = (uint32_t)(pball >> base) & 0x1ffu;
 #define BBME_SMOOTH_TERM(m) \
     { const uint32_t other = dpp_row<0x150 + (m)>(mine); if ((pmask >> (m)) & 1u) smooth = __builtin_amdgcn_sad_u16(other, mine, smooth); }
-    BBME_SMOOTH_TERM(0) BBME_SMOOTH_TERM(1) BBME_SMOOTH_TERM(2) BBME_SMOOTH_TERM(3) BBME_SMOOTH_TERM(4)
-    BBME_SMOOTH_TERM(5) BBME_SMOOTH_TERM(6) BBME_SMOOTH_TERM(7) BBME_SMOOTH_TERM(8)
+        BBME_SMOOTH_TERM(0) BBME_SMOOTH_TERM(1) BBME_SMOOTH_TERM(2) BBME_SMOOTH_TERM(3) BBME_SMOOTH_TERM(4)
+        BBME_SMOOTH_TERM(5) BBME_SMOOTH_TERM(6) BBME_SMOOTH_TERM(7) BBME_SMOOTH_TERM(8)
 #undef BBME_SMOOTH_TERM
+    }
     float e = 3.402823466e+38f;                                                 // FLT_MAX :580
     if (inside) {
         const float t = a.lambda_mult * (float)smooth;
         e = (float)sad + t;                                                     // :607
     }
-    // energies are >= 0, so their bit patterns order like the floats; absent lanes sort last.  The keys
-    // (energy, k) are distinct, so every lane of the row ends with the same winner whatever the order of
-    // the four exchanges: partner in the pair, in the quad, in the half row, in the row
-    uint32_t ebits = present ? __float_as_uint(e) : 0xffffffffu;
-    uint32_t who = (uint32_t)k16;
-    mv_t winner = mv;
-#define BBME_ARGMIN_STEP(ctrl) \
-    { const uint32_t oe = dpp_row<ctrl>(ebits), ow = dpp_row<ctrl>(who), om = dpp_row<ctrl>(winner); \
-      if (oe < ebits || (oe == ebits && ow < who)) { ebits = oe; who = ow; winner = om; } }
-    BBME_ARGMIN_STEP(0xB1)      // quad_perm [1,0,3,2]
-    BBME_ARGMIN_STEP(0x4E)      // quad_perm [2,3,0,1]
-    BBME_ARGMIN_STEP(0x141)     // row_half_mirror
-    BBME_ARGMIN_STEP(0x140)     // row_mirror
-#undef BBME_ARGMIN_STEP
+    // energies are >= 0, so their bit patterns order like the floats; absent lanes sort last.  Three all-reduces over the
+    // row of 16 lanes (partner in the pair, in the quad, in the half row, in the row), each a single DPP-fused instruction per
+    // step: the lowest energy; the lowest candidate index that has it (first strict minimum, :648-660); that candidate's MV
+    const uint32_t ebits = present ? __float_as_uint(e) : 0xffffffffu;
+    uint32_t emin = ebits;
+#define BBME_ROW_ALLREDUCE(var, op) \
+    var = op(var, dpp_row<0xB1>(var)); var = op(var, dpp_row<0x4E>(var)); var = op(var, dpp_row<0x141>(var)); var = op(var, dpp_row<0x140>(var));
+    BBME_ROW_ALLREDUCE(emin, min)
+    uint32_t who = ebits == emin ? (uint32_t)k16 : 15u;      // candidate 0 is always present, so emin belongs to a present one
+    BBME_ROW_ALLREDUCE(who, min)
+    uint32_t wmv = (uint32_t)k16 == who ? mv : 0u;
+#define BBME_OR(a, b) ((a) | (b))
+    BBME_ROW_ALLREDUCE(wmv, BBME_OR)
+#undef BBME_OR
+#undef BBME_ROW_ALLREDUCE
+    const mv_t winner = wmv;
     BBME_PHASE(prof, 2);                                      // smoothness + energy + argmin
     return winner;
 }
