@@ -69,6 +69,7 @@ struct bbme_ctx {
     size_t flag_bytes = 0;
     int relax_steps = -1;                         // k_reg_iter launches per sweep; -1 = by grid size (BBME_RELAX_STEPS overrides)
     bool split_forced = false;                    // threshold given in the environment: split whatever the plans' lengths (tests)
+    long long pass1_lanes_max = 140000;           // grids of at most this many blocks: pass 1 in the chain form (BBME_PASS1_LANES_MAX)
     int split_blocks = 10000;                     // levels of at most this many macroblocks: two waves per block (BBME_SEARCH_SPLIT_BLOCKS)
     int round_cap = 0;                            // > 0: test knob, the regulariser's waves give up after this many rounds
     uint32_t *own = nullptr;                      // ownership counters of the solver, one word per block
@@ -258,7 +259,7 @@ int launch_search(bbme_ctx *c, int level, int mode = kSearchPlain, hipStream_t s
 
 template <int BS>
 void launch_sweep_t(RegArgs a, uint8_t *const flags[2], int relax_steps, int max_solve_wgs, int solve_waves, bool jacobi,
-                    hipStream_t s)
+                    long long lanes_max, hipStream_t s)
 {
     constexpr int LPB = RegCfg<BS>::LPB;
     const long long blocks = (long long)a.rows * a.cols;
@@ -267,14 +268,22 @@ void launch_sweep_t(RegArgs a, uint8_t *const flags[2], int relax_steps, int max
     const int grid2 = (int)((std::min<long long>(max_solve_wgs, (blocks + 63) / 64) + 7) / 8 * 8);
     // pass 1 marks flags[0]; relaxation step i consumes flags[i & 1] and marks the other; the solver
     // consumes what the last step marked.  Every flag is zero again afterwards.
+    // grids up to ~130 000 blocks: the chain form of pass 1 (a third of the instructions per wave; 16 lanes per block fill the
+    // chip from ~32 000 blocks on, and it still wins up to four times that: 1.815 -> 1.78 ms per cfg3 pair; slower from 500 000)
+    auto pass1 = [&]() {
+        if (blocks <= lanes_max)
+            hipLaunchKernelGGL(k_reg_pass1_lanes<BS>, dim3((unsigned)((blocks * 16 + 255) / 256)), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL(k_reg_pass1<BS>, dim3(grid1), dim3(256), 0, s, a);
+    };
     if (jacobi) {
         // opt-in, NOT the reference's field: every block against the field as the previous sweep left it, and no more
         a.flag_cur = nullptr; a.flag_next = nullptr;
-        hipLaunchKernelGGL(k_reg_pass1<BS>, dim3(grid1), dim3(256), 0, s, a);
+        pass1();
         return;
     }
     a.flag_cur = nullptr; a.flag_next = flags[0];
-    hipLaunchKernelGGL(k_reg_pass1<BS>, dim3(grid1), dim3(256), 0, s, a);
+    pass1();
     int cur = 0;
     for (int i = 0; i < relax_steps; ++i, cur ^= 1) {
         a.flag_cur = flags[cur]; a.flag_next = flags[cur ^ 1];
@@ -338,12 +347,12 @@ int launch_sweep(bbme_ctx *c, int level, int b, int mult)
         steps = (nblk >= min_blocks && b <= max_b) ? (mult == 1 ? s1 : s2) : 0;
     }
     switch (b) {
-    case 2:  launch_sweep_t<2>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->stream); break;
-    case 4:  launch_sweep_t<4>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->stream); break;
-    case 8:  launch_sweep_t<8>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->stream); break;
-    case 16: launch_sweep_t<16>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->stream); break;
-    case 32: launch_sweep_t<32>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->stream); break;
-    case 64: launch_sweep_t<64>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->stream); break;
+    case 2:  launch_sweep_t<2>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->stream); break;
+    case 4:  launch_sweep_t<4>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->stream); break;
+    case 8:  launch_sweep_t<8>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->stream); break;
+    case 16: launch_sweep_t<16>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->stream); break;
+    case 32: launch_sweep_t<32>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->stream); break;
+    case 64: launch_sweep_t<64>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->stream); break;
     default: return bbme::fail(BBME_ERR_UNSUPPORTED, "block size %d", b);
     }
     HIP_TRY(hipGetLastError());
@@ -488,6 +497,7 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
     if (const char *e = getenv("BBME_RELAX_STEPS")) c->relax_steps = std::max(0, std::min(64, atoi(e)));
     if (const char *e = getenv("BBME_SOLVE_WAVES")) { const int v = atoi(e); c->solve_waves = v <= 1 ? 1 : (v == 2 ? 2 : 4); }
     if (const char *e = getenv("BBME_TEST_ROUND_CAP")) c->round_cap = std::max(0, atoi(e));
+    if (const char *e = getenv("BBME_PASS1_LANES_MAX")) c->pass1_lanes_max = atoll(e);
     if (const char *e = getenv("BBME_SEARCH_SPLIT_BLOCKS")) { c->split_blocks = std::max(0, atoi(e)); c->split_forced = true; }
     if (const char *e = getenv("BBME_NO_GRAPH")) c->use_graph = atoi(e) == 0;
     if (const char *e = getenv("BBME_SPECULATE")) c->speculate = atoi(e) != 0;

@@ -965,6 +965,26 @@ __global__ __launch_bounds__(256) void k_reg_pass1(RegArgs a)
 // launch, a barrier apart), those outside in the byte map flag_next for the next launch.  After `local_rounds`
 // rounds whatever is still queued goes to flag_next too.  Plain loads and stores.  An estimate outside the tile is
 // read once, at the start; if its owner changes it during this launch, that owner marks the reader in flag_next.
+// Pass 1 in the chain form (16 lanes per block, lane k = candidate k), for grids too small to fill the chip: there the launch
+// lasts as long as one wave's instruction stream does, and the chain form's is a third as long as eval_block's.
+template <int BS>
+__global__ __launch_bounds__(256) void k_reg_pass1_lanes(RegArgs a)
+{
+    __builtin_amdgcn_s_setprio(2);
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t < 16 && t != 5) a.counters[t] = 0;                  // as k_reg_pass1
+    const long long g = t >> 4;
+    const int k16 = (int)(t & 15);
+    if (g >= (long long)a.rows * a.cols) return;              // whole groups drop out together
+    const int r = (int)(g / a.cols), c = (int)(g % a.cols);
+    const mv_t res = eval_block_lanes<BS, false>(a, r, c, k16, 0u);
+    if (k16 == 0) {
+        a.est[g] = res;
+        const mv_t old = a.old_grid[(size_t)(r >> a.old_shift) * a.old_cols + (c >> a.old_shift)];
+        if (a.flag_next && res != old) mark_dependants(a, a.flag_next, r, c);
+    }
+}
+
 // This is asynchronous fixed-point iteration: any number of rounds or launches, followed by k_reg_solve, ends at
 // the same (unique) field.  It takes the first, heavy generations of a sweep -- thousands of stale blocks at once --
 // away from the solver, whose coherent traffic and memory-side atomics queue up under that load.
