@@ -171,11 +171,15 @@ def test_random_configurations_twice(bbme, oracle, seed):
     # the tile-resident relaxation launches before the solver (by default only on grids of >= 100 000 blocks at b <= 4)
     # forced into every sweep: any number of them must leave the result untouched
     for steps in ("1", "3"):
+        # ... and with the speculative search forced onto every level (by default only levels with >= 8 G abs-diffs of
+        # search work): every block's search starts early from a provisional prediction, the blocks whose prediction
+        # changed are searched again, and the result must still be the search from the final prediction
         os.environ["BBME_RELAX_STEPS"], os.environ["BBME_SEARCH_SPLIT_BLOCKS"] = steps, "100000000"
+        os.environ["BBME_SPEC_MIN_GABS"] = "0"
         try:
             mf = bbme.MF(f1, f2, search, blocks, L)
         finally:
-            del os.environ["BBME_RELAX_STEPS"], os.environ["BBME_SEARCH_SPLIT_BLOCKS"]
+            del os.environ["BBME_RELAX_STEPS"], os.environ["BBME_SEARCH_SPLIT_BLOCKS"], os.environ["BBME_SPEC_MIN_GABS"]
         for lvl in range(L):
             mf.set_level_planes(lvl, omf.image(lvl, 1), omf.image(lvl, 2))
         c = mf.calcMotionBlockMatching()
