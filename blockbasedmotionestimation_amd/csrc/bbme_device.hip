@@ -292,7 +292,10 @@ void launch_sweep_t(RegArgs a, uint8_t *const flags[2], int relax_steps, int max
         hipLaunchKernelGGL(k_reg_iter<BS>, dim3(tiles), dim3(256), 0, s, a);
     }
     a.flag_cur = flags[cur]; a.flag_next = nullptr;
-    hipLaunchKernelGGL(k_reg_solve<BS>, dim3(grid2), dim3(64 * solve_waves), 0, s, a);
+    // small grids: scan segments of 4 flags, so that the stale blocks of a row are dealt to four times as many waves
+    static const long long fine_max = getenv("BBME_SCAN_FINE_MAX") ? atoll(getenv("BBME_SCAN_FINE_MAX")) : 140000;
+    if (blocks <= fine_max) hipLaunchKernelGGL((k_reg_solve<BS, 4>), dim3(grid2), dim3(64 * solve_waves), 0, s, a);
+    else hipLaunchKernelGGL((k_reg_solve<BS, 16>), dim3(grid2), dim3(64 * solve_waves), 0, s, a);
 }
 
 int launch_sweep(bbme_ctx *c, int level, int b, int mult)

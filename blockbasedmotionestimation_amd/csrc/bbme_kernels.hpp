@@ -1167,9 +1167,10 @@ __device__ __forceinline__ void drain_lists(const RegArgs &a, int t, int nthread
 // s belongs to wave s mod W of that XCD, so that a cluster of stale blocks is spread over many waves
 // instead of queueing up behind one, and a wave looks at 64 of its segments -- 1024 flags -- per memory
 // trip: a sweep that left nothing stale costs two trips at 2 M blocks, not 127.
-template <int BS>
+template <int BS, int SEG = 16>
 __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
 {
+    static_assert(SEG == 16 || SEG == 4, "flags per scan segment");
     // two forms of a round: WIDE (eval_block: LPBW lanes per block, 64/LPBW blocks per round) when
     // the queue is long and throughput counts, LANES (eval_block_lanes: 16 lanes per block, lane k =
     // candidate k, 4 blocks per round) when it is short and the wave is walking a chain
@@ -1187,7 +1188,7 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
     const uint32_t xcd = blockIdx.x & 7u;                  // the launch has a multiple of 8 workgroups
     const uint32_t wpw = blockDim.x >> 6;                  // waves per workgroup (1, 2 or 4)
     const uint32_t wx = (blockIdx.x >> 3) * wpw + wave, Wx = (gridDim.x >> 3) * wpw;
-    const uint32_t nseg = (nblocks + 15u) / 16u, band = (nseg + 7u) / 8u;
+    const uint32_t nseg = (nblocks + (uint32_t)SEG - 1u) / (uint32_t)SEG, band = (nseg + 7u) / 8u;
     const uint32_t seg_begin = min(xcd * band, nseg), seg_end = min(seg_begin + band, nseg);
     uint32_t *ovf_list = a.list0;
     uint32_t *ovf_count = &a.counters[1];
@@ -1222,22 +1223,29 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
     for (uint32_t k = 0;; ++k) {
         if (seg_begin + k * 64u * Wx + wx < seg_end) {
             const uint32_t sg = seg_begin + (k * 64u + (uint32_t)lane) * Wx + wx;
+            // SEG = 4 on small grids: a cluster of stale blocks in a row is dealt to four times as many waves
             uint4 f = make_uint4(0, 0, 0, 0);
-            uint4 *fp = reinterpret_cast<uint4 *>(a.flag_cur + (size_t)sg * 16);      // the map is padded to whole segments
-            if (sg < seg_end) f = *fp;
+            uint8_t *fp = a.flag_cur + (size_t)sg * SEG;                               // the map is padded to whole 16-flag segments
+            if (sg < seg_end) {
+                if constexpr (SEG == 16) f = *reinterpret_cast<uint4 *>(fp);
+                else f.x = *reinterpret_cast<uint32_t *>(fp);
+            }
             const bool any = (f.x | f.y | f.z | f.w) != 0;
             if (__ballot(any)) {
-                if (any) *fp = make_uint4(0, 0, 0, 0);
+                if (any) {
+                    if constexpr (SEG == 16) *reinterpret_cast<uint4 *>(fp) = make_uint4(0, 0, 0, 0);
+                    else *reinterpret_cast<uint32_t *>(fp) = 0u;
+                }
                 const uint32_t fw[4] = {f.x, f.y, f.z, f.w};
                 // every claim of the step in flight at once (one memory trip), then the queue
-                uint32_t was[16];
+                uint32_t was[SEG];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
+                for (int j = 0; j < SEG; ++j) {
                     was[j] = 1;
-                    if ((fw[j >> 2] >> (8 * (j & 3))) & 0xffu) was[j] = own_claim(a, sg * 16u + (uint32_t)j);
+                    if ((fw[j >> 2] >> (8 * (j & 3))) & 0xffu) was[j] = own_claim(a, sg * (uint32_t)SEG + (uint32_t)j);
                 }
 #pragma unroll
-                for (int j = 0; j < 16; ++j) enqueue(was[j] == 0, sg * 16u + (uint32_t)j);
+                for (int j = 0; j < SEG; ++j) enqueue(was[j] == 0, sg * (uint32_t)SEG + (uint32_t)j);
             }
         } else if (head == tail) {
             break;
