@@ -236,6 +236,7 @@ def main():
                                 [block] * levels, levels, device=local_rank, frames_on_device=True))
         for c in ctxs:
             c.set_speculation(False)              # with pairs in flight the chip is busy anyway
+            c.set_relaxation(False)
             c.estimate_async()
         for c in ctxs:
             c.synchronize()
@@ -255,6 +256,7 @@ def main():
         for c in ctxs[1:]:
             c.close()
         mf.set_speculation(True)
+        mf.set_relaxation(True)
 
     # the boundary with host buffers (never `value`): frames in (pinned) host memory -> upload (2 x 8.3 MB at 4K), padding +
     # pyramid on the GPU, estimate, download of the dense field (66.8 MB) or of the compact 2x2-cell grid (4.2 MB)

@@ -84,6 +84,7 @@ struct bbme_ctx {
     bool raster_search = false;                   // MF::find_min_block (:246-294) instead of the spiral search; bbme_set_search_mode
     bool force_generic_search = false;            // BBME_GENERIC_SEARCH=1: use k_search_generic everywhere
     bool use_graph = true;
+    bool relax = true;                            // relaxation launches (k_reg_iter) on large grids of small blocks; bbme_set_relaxation
     bool speculate = true;                        // overlap every level's search with the coarser level's late sweeps; BBME_SPECULATE
     hipStream_t side_stream = nullptr;            // the speculative searches
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -347,7 +348,7 @@ int launch_sweep(bbme_ctx *c, int level, int b, int mult)
             return true;
         }();
         (void)parsed;
-        steps = (nblk >= min_blocks && b <= max_b) ? (mult == 1 ? s1 : s2) : 0;
+        steps = (c->relax && nblk >= min_blocks && b <= max_b) ? (mult == 1 ? s1 : s2) : 0;
     }
     switch (b) {
     case 2:  launch_sweep_t<2>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->stream); break;
@@ -682,6 +683,17 @@ int bbme_set_speculation(bbme_ctx *c, int enabled)
     drop_graph(c);                                   // the launch sequence changes
     c->speculate = enabled != 0;
     if (!c->speculate && c->side_stream) { (void)hipStreamDestroy(c->side_stream); c->side_stream = nullptr; }
+    return BBME_OK;
+}
+
+int bbme_set_relaxation(bbme_ctx *c, int enabled)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (c->relax == (enabled != 0)) return BBME_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    drop_graph(c);                                   // the launch sequence changes
+    c->relax = enabled != 0;
     return BBME_OK;
 }
 

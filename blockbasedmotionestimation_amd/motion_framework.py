@@ -103,6 +103,11 @@ class MF:
         """Speculative search of the next finer level beside a level's late sweeps (bbme_set_speculation); same result."""
         _capi.check(self._lib.bbme_set_speculation(self._ctx, int(bool(enabled))))
 
+    def set_relaxation(self, enabled):
+        """Scheduling only (same field): the relaxation launches in front of the solver on large grids of small blocks.
+        Turn them off, like the speculation, when several pairs are in flight on the GPU."""
+        _capi.check(self._lib.bbme_set_relaxation(self._ctx, 1 if enabled else 0))
+
     def set_stream(self, hip_stream_handle):
         _capi.check(self._lib.bbme_set_stream(self._ctx, C.c_void_p(hip_stream_handle)))
 

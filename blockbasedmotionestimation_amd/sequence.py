@@ -165,6 +165,7 @@ def estimate_pairs_pipelined(pairs, search_size, block_size, device=None, in_fli
                 slot = len(slots) - 1
                 if in_flight > 1:
                     slots[slot].set_speculation(False)      # the other pairs in flight fill the chip already
+                    slots[slot].set_relaxation(False)
             else:
                 slot = pending[0][0]
                 collect()

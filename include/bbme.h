@@ -163,6 +163,11 @@ int bbme_set_regularizer_mode(bbme_ctx *ctx, int mode);
  * shorter single pairs (the late sweeps leave most of the chip idle).  Turn it off when several contexts keep the chip
  * busy anyway (sequences with pairs in flight). */
 int bbme_set_speculation(bbme_ctx *ctx, int enabled);
+/* Scheduling option (default on): the relaxation launch (k_reg_iter) in front of the solver on large grids of small blocks takes
+ * the heavy first generations of a sweep off the solver's latency-bound waves at the price of chip-wide work.  Same field,
+ * bit for bit.  Turn it off, like the speculation, when several contexts keep the chip busy (8 pairs in flight at 4K:
+ * 31.6 -> 33.2 Mblocks/s). */
+int bbme_set_relaxation(bbme_ctx *ctx, int enabled);
 /* Orders the ctx stream behind everything enqueued so far on another HIP stream of the same device (NULL = the default
  * stream): call it before bbme_set_frames_device when the frames were produced by asynchronous work on that stream.
  * Without it the caller must have synchronised the producer itself. */

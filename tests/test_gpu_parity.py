@@ -734,7 +734,7 @@ def test_jacobi_fast_mode_is_what_it_says(bbme, oracle):
 def test_8k_pair_schedule_independence(bbme):
     """7680x4320, five levels (8.4 M 2x2 cells at level 0: every buffer, grid and list at four times the bench's size).  Too
     large for the oracle to check in seconds, so the properties that hold for any correct schedule: the same field on a
-    second run, with the speculative search off, and with a single-wave solver; and the Jacobi mode differs."""
+    second run, with the speculative search off, with the relaxation launches off, and with a single-wave solver; and the Jacobi mode differs."""
     import os
     f1, f2, _ = bbme.synth_pair(7680, 4320, 77, max_motion=24)
     search, block = [80] * 5, [16] * 5
@@ -743,6 +743,9 @@ def test_8k_pair_schedule_independence(bbme):
     assert np.array_equal(mf.calcMotionBlockMatching(), a)
     mf.set_speculation(False)
     assert np.array_equal(mf.calcMotionBlockMatching(), a)
+    mf.set_relaxation(False)
+    assert np.array_equal(mf.calcMotionBlockMatching(), a)
+    mf.set_relaxation(True)
     mf.set_regularizer_mode(True)
     assert not np.array_equal(mf.calcMotionBlockMatching(), a)
     mf.close()
