@@ -272,7 +272,7 @@ void launch_sweep_t(RegArgs a, uint8_t *const flags[2], int relax_steps, int max
     // grids up to ~130 000 blocks: the chain form of pass 1 (a third of the instructions per wave; 16 lanes per block fill the
     // chip from ~32 000 blocks on, and it still wins up to four times that: 1.815 -> 1.78 ms per cfg3 pair; slower from 500 000)
     auto pass1 = [&]() {
-        if (blocks <= lanes_max)
+        if (BS <= 16 && blocks <= lanes_max)               // (b >= 32: a lane would walk 32+ rows -- 13 against 6 us at b = 32)
             hipLaunchKernelGGL(k_reg_pass1_lanes<BS>, dim3((unsigned)((blocks * 16 + 255) / 256)), dim3(256), 0, s, a);
         else
             hipLaunchKernelGGL(k_reg_pass1<BS>, dim3(grid1), dim3(256), 0, s, a);
