@@ -949,11 +949,46 @@ __global__ __launch_bounds__(256) void k_reg_pass1(RegArgs a)
     const int sub = (int)(t % LPB);
     if (g >= (long long)a.rows * a.cols) return;   // whole groups drop out together (LPB | 256)
     const int r = (int)(g / a.cols), c = (int)(g % a.cols);
-    const mv_t res = eval_block<BS, false, true>(a, r, c, sub, 0u);
+    mv_t res, old;
+    if (r >= 1 && r + 1 < a.rows && c >= 1 && c + 1 < a.cols) {
+        // away from the border all nine candidates exist and come from the old grid: three 12-byte loads (or, when the old
+        // grid is the parent grid, the 2 x 2 parent cells around the block: two 8-byte loads) instead of nine
+        mv_t cand[9];
+        if (a.old_shift == 0) {
+            struct __attribute__((packed, aligned(1))) tri_t { uint32_t v[3]; };
+            const mv_t *p = a.old_grid + (size_t)(r - 1) * a.old_cols + (c - 1);
+            tri_t row[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) row[i] = *reinterpret_cast<const tri_t *>(p + (size_t)i * a.old_cols);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) cand[k] = row[1 + kNbRow[k]].v[1 + kNbCol[k]];
+        } else {
+            struct __attribute__((packed, aligned(1))) duo_t { uint32_t v[2]; };
+            const int pr0 = (r - 1) >> 1, pc0 = (c - 1) >> 1;                // (r + 1) >> 1 == pr0 + 1, (c + 1) >> 1 == pc0 + 1
+            const mv_t *p = a.old_grid + (size_t)pr0 * a.old_cols + pc0;
+            const duo_t w0 = *reinterpret_cast<const duo_t *>(p), w1 = *reinterpret_cast<const duo_t *>(p + a.old_cols);
+            const int ro = r & 1, co = c & 1;                                 // odd row: rows r-1, r in parent row pr0, r+1 in pr0 + 1
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                // neighbour row r + d lies in parent row pr0 + ((r + d) >> 1) - pr0: d = -1 -> 0, d = +1 -> 1, d = 0 -> 1 - (r & 1)
+                const int pr = kNbRow[k] < 0 ? 0 : kNbRow[k] > 0 ? 1 : 1 - ro;
+                const int pc = kNbCol[k] < 0 ? 0 : kNbCol[k] > 0 ? 1 : 1 - co;
+                const mv_t lo = pc ? w0.v[1] : w0.v[0], hi = pc ? w1.v[1] : w1.v[0];
+                cand[k] = pr ? hi : lo;
+            }
+        }
+        old = cand[0];
+        bool uniform = true;
+#pragma unroll
+        for (int k = 1; k < 9; ++k) uniform &= cand[k] == cand[0];
+        res = uniform ? cand[0] : score_block<BS, true>(a, cand, 0x1ffu, c * BS, r * BS, sub);
+    } else {
+        res = eval_block<BS, false, true>(a, r, c, sub, 0u);
+        old = a.old_grid[(size_t)(r >> a.old_shift) * a.old_cols + (c >> a.old_shift)];
+    }
     if (sub == 0) {
         a.est[g] = res;
         // the blocks that read this one as an already-updated input assumed the old value
-        const mv_t old = a.old_grid[(size_t)(r >> a.old_shift) * a.old_cols + (c >> a.old_shift)];
         if (a.flag_next && res != old) mark_dependants(a, a.flag_next, r, c);     // no map: the Jacobi fast mode stops here
     }
 }
