@@ -671,21 +671,39 @@ __device__ __forceinline__ mv_t score_block(const RegArgs &a, const mv_t (&cand)
     // calculate_smoothness (:623-644) with v_sad_u16 on bias-shifted halves: |u_m-u_k| + |v_m-v_k|
     int best = -1;
     float best_e = 0.f;
+    if (present == 0x1ffu) {
+        // away from the grid's border (nearly every block): all nine candidates exist -- 81 unconditional terms
+        uint32_t cb[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        if (!((present >> k) & 1u)) continue;
-        float e = 3.402823466e+38f;                                              // FLT_MAX :580
-        if ((inside >> k) & 1u) {
-            const uint32_t ck = cand[k] ^ 0x80008000u;
+        for (int k = 0; k < 9; ++k) cb[k] = cand[k] ^ 0x80008000u;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
             uint32_t smooth = 0;
 #pragma unroll
             for (int m = 0; m < 9; ++m)
-                if ((present >> m) & 1u)
-                    smooth = __builtin_amdgcn_sad_u16(cand[m] ^ 0x80008000u, ck, smooth);
+                if (m != k) smooth = __builtin_amdgcn_sad_u16(cb[m], cb[k], smooth);
             const float t = a.lambda_mult * (float)smooth;
-            e = energy[k] + t;                                                   // :607
+            float e = energy[k] + t;                                             // :607
+            if (!((inside >> k) & 1u)) e = 3.402823466e+38f;                     // FLT_MAX :580
+            if (k == 0 || e < best_e) { best = k; best_e = e; }                 // first strict min :648-660
         }
-        if (best < 0 || e < best_e) { best = k; best_e = e; }                   // first strict min :648-660
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (!((present >> k) & 1u)) continue;
+            float e = 3.402823466e+38f;                                          // FLT_MAX :580
+            if ((inside >> k) & 1u) {
+                const uint32_t ck = cand[k] ^ 0x80008000u;
+                uint32_t smooth = 0;
+#pragma unroll
+                for (int m = 0; m < 9; ++m)
+                    if ((present >> m) & 1u)
+                        smooth = __builtin_amdgcn_sad_u16(cand[m] ^ 0x80008000u, ck, smooth);
+                const float t = a.lambda_mult * (float)smooth;
+                e = energy[k] + t;                                               // :607
+            }
+            if (best < 0 || e < best_e) { best = k; best_e = e; }               // first strict min :648-660
+        }
     }
     mv_t res = cand[0];
 #pragma unroll
