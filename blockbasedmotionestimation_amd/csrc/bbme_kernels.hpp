@@ -587,6 +587,14 @@ __device__ __forceinline__ mv_t load_est(const mv_t *p)
         return *p;
 }
 
+// DPP move within a row of 16 lanes (CTRL: quad_perm 0x00-0xff, row_mirror 0x140, row_half_mirror 0x141,
+// row_newbcast:n 0x150+n).  All 16 lanes of a row must be active.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_row(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true);
+}
+
 // Score the (up to nine) candidates of block (bx, by) and return the winner: find_min_candidate,
 // calculate_smoothness, min_energy_candidate (motion_framework.cpp:532-662).  All LPB lanes of the
 // block's group call it; `sub` is the lane's row inside the block; `present` marks the neighbours
@@ -653,10 +661,14 @@ __device__ __forceinline__ mv_t score_block(const RegArgs &a, const mv_t (&cand)
 #pragma unroll
             for (int q = 0; q < NW; ++q)
                 sad = __builtin_amdgcn_sad_u8(cur[i].v[q] & kMask, win[k][i].v[q] & kMask, sad);
-        if constexpr (LPB > 1) {
-#pragma unroll
-            for (int o = LPB / 2; o > 0; o >>= 1) sad += __shfl_xor(sad, o);
-        }
+        // sum over the block's LPB lanes (aligned groups inside a DPP row of 16): partner in the pair, in the quad, in the
+        // half row, in the row -- VALU moves instead of LDS shuffles -- and across rows for the larger blocks
+        if constexpr (LPB >= 2) sad += dpp_row<0xB1>(sad);
+        if constexpr (LPB >= 4) sad += dpp_row<0x4E>(sad);
+        if constexpr (LPB >= 8) sad += dpp_row<0x141>(sad);
+        if constexpr (LPB >= 16) sad += dpp_row<0x140>(sad);
+        if constexpr (LPB >= 32) sad += __shfl_xor(sad, 16);
+        if constexpr (LPB >= 64) sad += __shfl_xor(sad, 32);
         energy[k] = (float)sad;
     }
     if constexpr (DEDUP) {
@@ -744,14 +756,6 @@ __device__ __forceinline__ mv_t eval_block(const RegArgs &a, int r, int c, int s
 // of 16 lanes and lane k < 9 owns candidate k: its address arithmetic, its image rows, its SAD, its
 // smoothness term (the other candidates arrive by shuffle) and its energy -- the same float expression
 // as in score_block, so the same winner: lowest energy, ties to the lowest k (:648-660).
-// DPP move within a row of 16 lanes (CTRL: quad_perm 0x00-0xff, row_mirror 0x140, row_half_mirror 0x141,
-// row_newbcast:n 0x150+n).  All 16 lanes of a row must be active.
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp_row(uint32_t x)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true);
-}
-
 // Phase profile of a LANES round (development aid, compiled only with -DBBME_PHASE_PROFILE): shader-clock
 // stamps, each after every outstanding memory operation has returned, summed per phase in counters[9..15].
 #ifdef BBME_PHASE_PROFILE
