@@ -69,6 +69,7 @@ struct bbme_ctx {
     size_t flag_bytes = 0;
     int relax_steps = -1;                         // k_reg_iter launches per sweep; -1 = by grid size (BBME_RELAX_STEPS overrides)
     bool split_forced = false;                    // threshold given in the environment: split whatever the plans' lengths (tests)
+    long long scan_fine_max = 140000;             // grids of at most this many blocks: scan segments of 4 flags (BBME_SCAN_FINE_MAX)
     long long pass1_lanes_max = 140000;           // grids of at most this many blocks: pass 1 in the chain form (BBME_PASS1_LANES_MAX)
     int split_blocks = 10000;                     // levels of at most this many macroblocks: two waves per block (BBME_SEARCH_SPLIT_BLOCKS)
     int round_cap = 0;                            // > 0: test knob, the regulariser's waves give up after this many rounds
@@ -260,7 +261,7 @@ int launch_search(bbme_ctx *c, int level, int mode = kSearchPlain, hipStream_t s
 
 template <int BS>
 void launch_sweep_t(RegArgs a, uint8_t *const flags[2], int relax_steps, int max_solve_wgs, int solve_waves, bool jacobi,
-                    long long lanes_max, hipStream_t s)
+                    long long lanes_max, long long fine_max, hipStream_t s)
 {
     constexpr int LPB = RegCfg<BS>::LPB;
     const long long blocks = (long long)a.rows * a.cols;
@@ -294,7 +295,6 @@ void launch_sweep_t(RegArgs a, uint8_t *const flags[2], int relax_steps, int max
     }
     a.flag_cur = flags[cur]; a.flag_next = nullptr;
     // small grids: scan segments of 4 flags, so that the stale blocks of a row are dealt to four times as many waves
-    static const long long fine_max = getenv("BBME_SCAN_FINE_MAX") ? atoll(getenv("BBME_SCAN_FINE_MAX")) : 140000;
     if (blocks <= fine_max) hipLaunchKernelGGL((k_reg_solve<BS, 4>), dim3(grid2), dim3(64 * solve_waves), 0, s, a);
     else hipLaunchKernelGGL((k_reg_solve<BS, 16>), dim3(grid2), dim3(64 * solve_waves), 0, s, a);
 }
@@ -351,12 +351,12 @@ int launch_sweep(bbme_ctx *c, int level, int b, int mult)
         steps = (c->relax && nblk >= min_blocks && b <= max_b) ? (mult == 1 ? s1 : s2) : 0;
     }
     switch (b) {
-    case 2:  launch_sweep_t<2>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->stream); break;
-    case 4:  launch_sweep_t<4>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->stream); break;
-    case 8:  launch_sweep_t<8>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->stream); break;
-    case 16: launch_sweep_t<16>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->stream); break;
-    case 32: launch_sweep_t<32>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->stream); break;
-    case 64: launch_sweep_t<64>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->stream); break;
+    case 2:  launch_sweep_t<2>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->stream); break;
+    case 4:  launch_sweep_t<4>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->stream); break;
+    case 8:  launch_sweep_t<8>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->stream); break;
+    case 16: launch_sweep_t<16>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->stream); break;
+    case 32: launch_sweep_t<32>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->stream); break;
+    case 64: launch_sweep_t<64>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->stream); break;
     default: return bbme::fail(BBME_ERR_UNSUPPORTED, "block size %d", b);
     }
     HIP_TRY(hipGetLastError());
@@ -502,6 +502,7 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
     if (const char *e = getenv("BBME_SOLVE_WAVES")) { const int v = atoi(e); c->solve_waves = v <= 1 ? 1 : (v == 2 ? 2 : 4); }
     if (const char *e = getenv("BBME_TEST_ROUND_CAP")) c->round_cap = std::max(0, atoi(e));
     if (const char *e = getenv("BBME_PASS1_LANES_MAX")) c->pass1_lanes_max = atoll(e);
+    if (const char *e = getenv("BBME_SCAN_FINE_MAX")) c->scan_fine_max = atoll(e);
     if (const char *e = getenv("BBME_SEARCH_SPLIT_BLOCKS")) { c->split_blocks = std::max(0, atoi(e)); c->split_forced = true; }
     if (const char *e = getenv("BBME_NO_GRAPH")) c->use_graph = atoi(e) == 0;
     if (const char *e = getenv("BBME_SPECULATE")) c->speculate = atoi(e) != 0;

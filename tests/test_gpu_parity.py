@@ -157,12 +157,12 @@ def test_random_configurations_twice(bbme, oracle, seed):
     # never here, and on every level in the relaxation runs below;
     # and the form of pass 1: the chain form by default on grids of this size, the throughput form here)
     os.environ["BBME_SOLVE_WGS"], os.environ["BBME_SOLVE_WAVES"], os.environ["BBME_SEARCH_SPLIT_BLOCKS"] = "1", "1", "0"
-    os.environ["BBME_PASS1_LANES_MAX"] = "0"
+    os.environ["BBME_PASS1_LANES_MAX"], os.environ["BBME_SCAN_FINE_MAX"] = "0", "0"      # ... and 16-flag scan segments
     try:
         mf = bbme.MF(f1, f2, search, blocks, L)
     finally:
         del os.environ["BBME_SOLVE_WGS"], os.environ["BBME_SOLVE_WAVES"], os.environ["BBME_SEARCH_SPLIT_BLOCKS"]
-        del os.environ["BBME_PASS1_LANES_MAX"]
+        del os.environ["BBME_PASS1_LANES_MAX"], os.environ["BBME_SCAN_FINE_MAX"]
     for lvl in range(L):
         mf.set_level_planes(lvl, omf.image(lvl, 1), omf.image(lvl, 2))
     c = mf.calcMotionBlockMatching()
