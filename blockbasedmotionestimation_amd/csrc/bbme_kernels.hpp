@@ -845,15 +845,24 @@ __device__ __forceinline__ mv_t lanes_score(const RegArgs &a, int r, int c, int 
     uint32_t sad0 = 0, sad1 = 0;                              // two chains: v_sad_u8 results feed the next one
     const uint8_t *p1 = a.image1 + (size_t)by * a.width + bx;
     const uint8_t *p2 = a.image2 + (size_t)y2 * a.width + x2;
+    // b <= 16: every row in flight at once.  b >= 32: eight rows at a time -- 2 x 32 rows of 8+ dwords do not fit the 256
+    // architectural registers, and the accumulation registers the compiler parks them in cost a copy each way
+    constexpr int CHUNK = BS >= 32 ? 8 : BS;
+    for (int row0 = 0; row0 < BS; row0 += CHUNK) {
+        row_t u[CHUNK], w[CHUNK];
 #pragma unroll
-    for (int row = 0; row < BS; ++row) {
-        const row_t u = *reinterpret_cast<const row_t *>(p1 + (size_t)row * a.width);
-        const row_t w = *reinterpret_cast<const row_t *>(p2 + (size_t)row * a.width);
-#pragma unroll
-        for (int q = 0; q < NW; ++q) {
-            if ((row + q) & 1) sad1 = __builtin_amdgcn_sad_u8(u.v[q] & kMask, w.v[q] & kMask, sad1);
-            else sad0 = __builtin_amdgcn_sad_u8(u.v[q] & kMask, w.v[q] & kMask, sad0);
+        for (int i = 0; i < CHUNK; ++i) {
+            u[i] = *reinterpret_cast<const row_t *>(p1 + (size_t)(row0 + i) * a.width);
+            w[i] = *reinterpret_cast<const row_t *>(p2 + (size_t)(row0 + i) * a.width);
         }
+#pragma unroll
+        for (int i = 0; i < CHUNK; ++i)
+#pragma unroll
+            for (int q = 0; q < NW; ++q) {
+                if ((i + q) & 1) sad1 = __builtin_amdgcn_sad_u8(u[i].v[q] & kMask, w[i].v[q] & kMask, sad1);
+                else sad0 = __builtin_amdgcn_sad_u8(u[i].v[q] & kMask, w[i].v[q] & kMask, sad0);
+            }
+        if constexpr (BS >= 32) asm volatile("" ::: "memory");   // keep the chunks apart
     }
     const uint32_t sad = sad0 + sad1;
     BBME_PHASE(prof, 1);                                      // row loads + SAD
