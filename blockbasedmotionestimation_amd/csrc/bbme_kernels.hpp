@@ -222,16 +222,13 @@ struct FastSearchArgs {
     int xcd_remap;              // 1 = XCD-aware block order
 };
 
-// Current block operand: B <= 16 keeps the block in SGPRs (cur), B = 32 reads it from LDS with
-// wave-uniform addresses (cur_lds, B*B/4 dwords).
+// Current block operand: B <= 16 keeps the whole block in SGPRs; B = 32 keeps its address, and search_strip brings the block
+// through the SGPRs eight rows at a time.
 template <int B> struct CurBlock {
     uint32_t sg[B <= 16 ? B : 1][B <= 16 ? B / 4 : 1];
-    const uint32_t *lds;
-    __device__ __forceinline__ uint32_t at(int row, int q) const
-    {
-        if constexpr (B <= 16) return sg[row][q];
-        else return lds[row * (B / 4) + q];
-    }
+    uint64_t base;              // B = 32: image1 (wave-uniform) and the byte offset of the block's first pixel: the strip
+    uint32_t off0, width;       // function loads the block eight rows at a time into SGPRs
+    __device__ __forceinline__ uint32_t at(int row, int q) const { return sg[row][q]; }
 };
 
 template <int B, int S>
@@ -240,10 +237,8 @@ __device__ __forceinline__ uint32_t search_strip(const uint32_t *win, int P, con
                                                  bool border, int xlo, int xhi, int ylo, int yhi)
 {
     constexpr int BW = B / 4;
-    // packed u16 sums hold at most 256 pixels (255 * 256 < 2^16): B = 32 flushes them into 32-bit sums
-    // after every 8 block rows
+    // packed u16 sums hold at most 256 pixels (255 * 256 < 2^16): B = 32 flushes them into 32-bit sums after every 8 block rows
     constexpr bool WIDE = B > 16;
-    constexpr int FLUSH = 256 / B;
     const bool idle = task == 0xffffffffu;
     const int g = idle ? 0 : (int)(task & 0xffu);
     const int dy0 = idle ? 0 : (int)((task >> 8) & 0xffu);
@@ -257,48 +252,90 @@ __device__ __forceinline__ uint32_t search_strip(const uint32_t *win, int P, con
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc32[d][c] = 0;
     }
+    struct __attribute__((packed, aligned(4))) pair_w { unsigned long long v; };
+    if constexpr (WIDE) {
+        // B = 32: the block does not fit the scalar registers (256 dwords), and read from LDS at every use it cost an LDS read
+        // per QSAD and -- fully unrolled over 39 window rows -- 512 registers plus scratch.  So the block goes through the
+        // SGPRs in four bands of eight rows (64 dwords, as a whole 16 x 16 block does): per band the strip walks the
+        // 8 + S - 1 window rows that meet it, the packed u16 sums (8 x 32 pixels: 255 * 256 < 2^16) are flushed into the
+        // 32-bit sums, and the next band is loaded.
+        typedef const uint32_t __attribute__((address_space(4))) *cptr_t;
+#pragma unroll 1
+        for (int band = 0; band < B / 8; ++band) {
+            uint32_t cb[8][BW];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                cptr_t c1 = (cptr_t)(cur.base + cur.off0 + (uint32_t)(band * 8 + r) * cur.width);
+#pragma unroll
+                for (int q = 0; q < BW; ++q) cb[r][q] = c1[q];
+            }
+            const uint32_t *wrow = win + (dy0 + band * 8) * P + g;
+            unsigned long long wn[BW];
+#pragma unroll
+            for (int q = 0; q < BW; ++q) wn[q] = reinterpret_cast<const pair_w *>(wrow + q)->v;
+            wrow += P;
+#pragma unroll
+            for (int yy = 0; yy < 8 + S - 1; ++yy) {
+                unsigned long long w[BW];
+#pragma unroll
+                for (int q = 0; q < BW; ++q) w[q] = wn[q];
+                if (yy + 1 < 8 + S - 1) {
+#pragma unroll
+                    for (int q = 0; q < BW; ++q) wn[q] = reinterpret_cast<const pair_w *>(wrow + q)->v;
+                    wrow += P;
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int d = 0; d < S; ++d) {
+                    const int brow = yy - d;                   // row of the band this window row meets
+                    if (brow < 0 || brow >= 8) continue;
+#pragma unroll
+                    for (int q = 0; q < BW; ++q)
+                        acc[d] = __builtin_amdgcn_qsad_pk_u16_u8(w[q], cb[brow][q], acc[d]);
+                    asm volatile("" : "+v"(acc[d]));
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < S; ++d) {
+                const uint32_t lo = (uint32_t)acc[d], hi = (uint32_t)(acc[d] >> 32);
+                acc32[d][0] += lo & 0xffffu; acc32[d][1] += lo >> 16;
+                acc32[d][2] += hi & 0xffffu; acc32[d][3] += hi >> 16;
+                acc[d] = 0;
+            }
+        }
+    }
     // One window row ahead is kept in flight.  The QSAD chains are pure, so the optimiser would
     // sink all of them below all of the LDS reads (150+ live VGPRs, occupancy gone); the empty asm
     // statements pin the order: reads of row yy+1, then the QSADs of row yy, row after row.
     // QSAD's first operand is the 8 window bytes at dword q of the row: dwords (q, q + 1) in one register pair.  Adjacent
     // operands overlap by a dword, so building them from BW + 1 loaded dwords costs a register copy each; loading every
     // pair on its own (ds_read2_b32 q, q + 1 straight into the pair) costs LDS reads instead, which are not the limit.
-    struct __attribute__((packed, aligned(4))) pair_t { unsigned long long v; };
-    const uint32_t *wrow = win + dy0 * P + g;
-    unsigned long long wn[BW];
+    if constexpr (!WIDE) {
+        const uint32_t *wrow = win + dy0 * P + g;
+        unsigned long long wn[BW];
 #pragma unroll
-    for (int q = 0; q < BW; ++q) wn[q] = reinterpret_cast<const pair_t *>(wrow + q)->v;
-    wrow += P;
+        for (int q = 0; q < BW; ++q) wn[q] = reinterpret_cast<const pair_w *>(wrow + q)->v;
+        wrow += P;
 #pragma unroll
-    for (int yy = 0; yy < B + S - 1; ++yy) {
-        unsigned long long w[BW];
+        for (int yy = 0; yy < B + S - 1; ++yy) {
+            unsigned long long w[BW];
 #pragma unroll
-        for (int q = 0; q < BW; ++q) w[q] = wn[q];
-        if (yy + 1 < B + S - 1) {
+            for (int q = 0; q < BW; ++q) w[q] = wn[q];
+            if (yy + 1 < B + S - 1) {
 #pragma unroll
-            for (int q = 0; q < BW; ++q) wn[q] = reinterpret_cast<const pair_t *>(wrow + q)->v;
-            wrow += P;
-        }
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int d = 0; d < S; ++d) {
-            const int brow = yy - d;                       // row of the current block this window row meets
-            if (brow < 0 || brow >= B) continue;
-            // B = 32: re-read the block row from LDS here (uniform address, cheap next to 24-cycle QSADs)
-            // instead of letting the compiler keep all 256 dwords of the block in VGPRs
-            if constexpr (WIDE) asm volatile("" ::: "memory");
-#pragma unroll
-            for (int q = 0; q < BW; ++q)
-                acc[d] = __builtin_amdgcn_qsad_pk_u16_u8(w[q], cur.at(brow, q), acc[d]);
-            if constexpr (WIDE) {
-                if ((brow % FLUSH) == FLUSH - 1) {
-                    const uint32_t lo = (uint32_t)acc[d], hi = (uint32_t)(acc[d] >> 32);
-                    acc32[d][0] += lo & 0xffffu; acc32[d][1] += lo >> 16;
-                    acc32[d][2] += hi & 0xffffu; acc32[d][3] += hi >> 16;
-                    acc[d] = 0;
-                }
+                for (int q = 0; q < BW; ++q) wn[q] = reinterpret_cast<const pair_w *>(wrow + q)->v;
+                wrow += P;
             }
-            asm volatile("" : "+v"(acc[d]));
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int d = 0; d < S; ++d) {
+                const int brow = yy - d;                   // row of the current block this window row meets
+                if (brow < 0 || brow >= B) continue;
+#pragma unroll
+                for (int q = 0; q < BW; ++q)
+                    acc[d] = __builtin_amdgcn_qsad_pk_u16_u8(w[q], cur.at(brow, q), acc[d]);
+                asm volatile("" : "+v"(acc[d]));
+            }
         }
     }
     // column validity: padding columns of the last group, and (near the image border) blocks leaving the image
@@ -412,27 +449,23 @@ __device__ __forceinline__ void search_block_fast(const FastSearchArgs &a, uint3
             }
         }
     }
-    // the current block: B <= 16: wave-uniform addresses -> scalar loads, lives in SGPRs;
-    // B = 32: 256 dwords, staged in LDS behind the window and read back with uniform addresses
+    // the current block: wave-uniform addresses of read-only data -> through the constant address space these are scalar
+    // loads (s_load_dwordx4 / x8 per block row) instead of a vector load + v_readfirstlane per dword.  B <= 16: the whole block
+    // lives in SGPRs from here on; B = 32: search_strip loads it band by band
     CurBlock<B> cur;
-    cur.lds = smem + wrows * P;
-    if constexpr (B <= 16) {
-        // wave-uniform addresses of read-only data: through the constant address space these are scalar loads
-        // (s_load_dwordx4 per block row) instead of a vector load + v_readfirstlane per dword
+    {
         typedef const uint32_t __attribute__((address_space(4))) *cptr_t;
         const uint64_t base = (uint64_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uintptr_t)a.image1 >> 32)) << 32 |
                               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)a.image1);
         const uint32_t off0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)i * (uint32_t)a.width + (uint32_t)j));
+        cur.base = base; cur.off0 = off0; cur.width = (uint32_t)a.width;
+        if constexpr (B <= 16) {
 #pragma unroll
-        for (int r = 0; r < B; ++r) {
-            cptr_t c1 = (cptr_t)(base + off0 + (uint32_t)r * (uint32_t)a.width);
+            for (int r = 0; r < B; ++r) {
+                cptr_t c1 = (cptr_t)(base + off0 + (uint32_t)r * (uint32_t)a.width);
 #pragma unroll
-            for (int q = 0; q < BW; ++q) cur.sg[r][q] = c1[q];
-        }
-    } else {
-        for (int idx = tid; idx < B * BW; idx += T) {
-            const int r = idx / BW, q = idx - r * BW;
-            smem[wrows * P + idx] = *reinterpret_cast<const uint32_t *>(a.image1 + (size_t)(i + r) * a.width + j + 4 * q);
+                for (int q = 0; q < BW; ++q) cur.sg[r][q] = c1[q];
+            }
         }
     }
     __syncthreads();
