@@ -560,8 +560,7 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
             L.rank_pitch = sp.rank_pitch;
             L.nrounds = (int)plan.rounds.size();
             L.fast_pitch_dw = plan.pitch_dw;
-            L.fast_lds_bytes = (size_t)(L.block + 2 * L.range) * plan.pitch_dw * 4 +
-                               (L.block == 32 ? (size_t)L.block * L.block : 0);   // B = 32: the current block too
+            L.fast_lds_bytes = (size_t)(L.block + 2 * L.range) * plan.pitch_dw * 4;   // the window; the block is in SGPRs
             if ((err = hipMalloc(&L.rank_of, sp.rank_of.size() * 2 + 64)) != hipSuccess ||
                 (err = hipMalloc(&L.tasks, plan.tasks.size() * 4)) != hipSuccess ||
                 (err = hipMalloc(&L.rounds, plan.rounds.size() * 4)) != hipSuccess ||
