@@ -1552,10 +1552,15 @@ __global__ __launch_bounds__(256) void k_pad_zero(PlanePair p, int width, int he
             }
         }
     }
-    uint32_t *out = reinterpret_cast<uint32_t *>(dst + (size_t)y * pw + x0);
+    uint8_t *o = dst + (size_t)y * pw + x0;
+    if (x0 + 16 <= pw && (((uintptr_t)o) & 15u) == 0) {               // the usual case: one 16-byte store
+        *reinterpret_cast<uint4 *>(o) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+        uint32_t *out = reinterpret_cast<uint32_t *>(o);
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-        if (x0 + 4 * q < pw) out[q] = w[q];
+        for (int q = 0; q < 4; ++q)
+            if (x0 + 4 * q < pw) out[q] = w[q];
+    }
 }
 
 __device__ __forceinline__ int mirror101(int p, int n)
