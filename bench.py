@@ -89,7 +89,25 @@ def epe_on_ground_truth(bbme, device, jacobi=False):
                     "4 levels, 32x32 blocks, search 64"}
 
 
+def cgroup_cpu_quota():
+    """(cores, text): the CPU-time quota of this job's control group in cores (None = unlimited) and the raw setting read --
+    cgroup v2 cpu.max ("max 100000" / "1600000 100000"), else v1 cpu.cfs_quota_us / cpu.cfs_period_us."""
+    try:
+        text = open("/sys/fs/cgroup/cpu.max").read().strip()
+        quota, period = text.split()[:2]
+        return (None if quota == "max" else float(quota) / float(period)), "cpu.max: " + text
+    except (OSError, ValueError):
+        pass
+    try:
+        quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return (None if quota <= 0 else quota / period), "cpu.cfs_quota_us / cpu.cfs_period_us: %d / %d" % (quota, period)
+    except (OSError, ValueError):
+        return None, "no cgroup cpu quota file"
+
+
 def cpu_info():
+    """model name, nproc, cores this job may really use = min(affinity mask, cgroup quota), and the quota as read."""
     model = None
     try:
         for line in open("/proc/cpuinfo"):
@@ -102,36 +120,92 @@ def cpu_info():
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = os.cpu_count()
-    return model, os.cpu_count(), usable
+    quota, quota_text = cgroup_cpu_quota()
+    if quota is not None:
+        usable = max(1, min(usable, int(quota + 0.5)))
+    return model, os.cpu_count(), usable, quota_text
+
+
+_NATIVE_ORACLE = {}
+
+
+def native_oracle(omp):
+    """The oracle's C restatement rebuilt for this host (-O3 -march=native; with OpenMP over the macroblocks of the search
+    when `omp`), loaded in place of the portable build.  Checker / CPU baseline only."""
+    from oracle import bbme_oracle as O
+    if omp not in _NATIVE_ORACLE:
+        src = os.path.join(ROOT, "oracle", "bbme_oracle.c")
+        out = os.path.join(tempfile.mkdtemp(prefix="bbme_cpu_"), "liboracle_native_%s.so" % ("omp" if omp else "st"))
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-shared", "-ffp-contract=off"] +
+                              (["-fopenmp"] if omp else []) + ["-o", out, src, "-lm"])
+        _NATIVE_ORACLE[omp] = out
+    O._LIB_PATH = _NATIVE_ORACLE[omp]
+    O._lib = None
+    return O
+
+
+def oracle_flow(f1, f2, search, block, levels, threads):
+    """(seconds, field) of the whole pyramid on the CPU oracle, timed as the reference times calcMotionBlockMatching
+    (main_class.cpp:47-55): threads == 1 like the reference; threads > 1: the search's macroblock loop spread with OpenMP
+    (the regulariser sweeps stay sequential: they are order dependent)."""
+    O = native_oracle(threads > 1)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    omf = O.OracleMF(f1, f2, [search] * levels, [block] * levels, use_cache=False)
+    t0 = time.perf_counter()
+    flow = omf.calc_motion_block_matching()
+    dt = time.perf_counter() - t0
+    omf.close()
+    return dt, flow
+
+
+def cpu_pool():
+    # every host core this job may use (affinity mask and cgroup quota, BASELINE.md section 2); BBME_CPU_THREADS overrides
+    return max(1, int(os.environ.get("BBME_CPU_THREADS", cpu_info()[2])))
 
 
 def cpu_baseline(f1, f2, search, block, levels, expect_flow):
-    """The oracle (CPU restatement, rebuilt here with -O3 -march=native) timed on the same pair, whole pyramid, as the
-    reference times calcMotionBlockMatching (main_class.cpp:47-55): (i) one thread, like the reference; (ii) the
-    search's macroblock loop spread over all usable host cores with OpenMP (the regulariser sweeps stay sequential:
-    they are order dependent).  Returns [(seconds, threads, parity)] for the two legs."""
-    from oracle import bbme_oracle as O
-    src = os.path.join(ROOT, "oracle", "bbme_oracle.c")
-    tmp = tempfile.mkdtemp(prefix="bbme_cpu_")
-    _, _, usable = cpu_info()
-    # a 1-GPU box gives this job a share of 16 host cores whatever nproc says; BBME_CPU_THREADS overrides
-    pool = max(1, min(usable, int(os.environ.get("BBME_CPU_THREADS", "16"))))
+    """The oracle timed on the same pair, whole pyramid: (i) one thread, like the reference; (ii) all usable host cores.
+    Returns [(seconds, threads, parity)] for the two legs."""
     legs = []
-    for name, flags, threads in (("st", [], 1), ("omp", ["-fopenmp"], pool)):
-        out = os.path.join(tmp, "liboracle_native_%s.so" % name)
-        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-shared", "-ffp-contract=off"] + flags +
-                              ["-o", out, src, "-lm"])
-        os.environ["OMP_NUM_THREADS"] = str(threads)
-        O._LIB_PATH = out            # load the native build instead of the portable one
-        O._lib = None
-        omf = O.OracleMF(f1, f2, [search] * levels, [block] * levels, use_cache=False)
-        t0 = time.perf_counter()
-        flow = omf.calc_motion_block_matching()
-        dt = time.perf_counter() - t0
-        omf.close()
+    for threads in (1, cpu_pool()):
+        dt, flow = oracle_flow(f1, f2, search, block, levels, threads)
         parity = bool(np.array_equal(flow, expect_flow)) if expect_flow is not None else None
         legs.append((dt, threads, parity))
     return legs
+
+
+def other_workload(bbme, torch, name, device, steps, warmup, check):
+    """One of the other single-GPU BASELINE configs, timed as `value` is (frames resident, graph replays, device sync on both
+    sides), a few steps; search / regulariser split from one eager HIP-event pass; `parity_vs_oracle` = the field against
+    the CPU oracle's on the same pair (all host cores), None when the CPU legs are switched off."""
+    w, h, search, block, levels, desc = WORKLOADS[name]
+    f1, f2, _ = bbme.synth_pair(w, h, 1000 + 30, max_motion=24)
+    mf = bbme.MF(torch.from_numpy(f1).cuda(), torch.from_numpy(f2).cuda(), [search] * levels, [block] * levels, levels,
+                 device=device, frames_on_device=True)
+    mf.synchronize()
+    for _ in range(warmup):
+        mf.estimate_async()
+    mf.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        mf.estimate_async()
+    mf.synchronize()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    flow = mf.get_flow()
+    mf.set_profiling(True)
+    mf.estimate_async()
+    prof = mf.timings()
+    mf.set_profiling(False)
+    blocks = level_blocks(mf.padded_width, mf.padded_height, block, levels)
+    mf.close()
+    parity = None
+    if check:
+        parity = bool(np.array_equal(oracle_flow(f1, f2, search, block, levels, cpu_pool())[1], flow))
+    return {"workload": desc, "value": round(blocks[0] / dt / 1e6, 4), "unit": "Mblocks/s", "ms_per_step": round(dt * 1e3, 4),
+            "steps": steps, "blocks_level0": blocks[0], "search_ms": round(prof["search_ms"], 4),
+            "regularize_ms": round(prof["regularize_ms"], 4), "parity_vs_oracle": parity}
 
 
 def main():
@@ -142,6 +216,7 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-iters", type=int, default=5)
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the `other_workloads` legs (cfg2, cfg4, cfg1, ref)")
     ap.add_argument("--no-host-boundary", action="store_true",
                     help="skip the host_boundary legs (for kernel traces: their pyramids start from freshly uploaded frames)")
     ap.add_argument("--in-flight", type=int, default=8,
@@ -453,9 +528,14 @@ def main():
                                        "cells_differing_from_exact": round(float((jac_flow != result_flow).any(-1).mean()), 5),
                                        "epe_vs_middlebury_gt": epe_j["value"] if epe_j else None,
                                        "epe_exact": out["epe_vs_middlebury_gt"]["value"] if out["epe_vs_middlebury_gt"] else None}
+        if not use_dist and not args.no_other_workloads:
+            # the other single-GPU BASELINE configs (never `value`): the driver's one command times them all
+            out["other_workloads"] = {name: other_workload(bbme, torch, name, local_rank, max(4, args.steps // 4), 3,
+                                                           not args.no_cpu_baseline)
+                                      for name in ("cfg2", "cfg4", "cfg1", "ref") if name != args.workload}
         if not args.no_cpu_baseline:
             (dt1, _, par1), (dtn, threads, parn) = cpu_baseline(f1, f2, search, block, levels, result_flow)
-            model, nproc, usable = cpu_info()
+            model, nproc, usable, quota_text = cpu_info()
             out["cpu_baseline"] = {"value": round(blocks[0] / dt1 / 1e6, 5), "unit": "Mblocks/s", "cores": 1,
                                    "kind": "port", "seconds": round(dt1, 2),
                                    "sample": "the same full %s pair, whole pyramid, oracle/bbme_oracle.c "
@@ -464,7 +544,7 @@ def main():
                                                  "cores": threads, "seconds": round(dtn, 2),
                                                  "note": "same pair; OpenMP over the macroblocks of the search "
                                                          "(calcLevelBM), regulariser sweeps sequential"},
-                                   "host": {"cpu_model": model, "nproc": nproc, "usable_cores": usable}}
+                                   "host": {"cpu_model": model, "nproc": nproc, "usable_cores": usable, "cgroup_quota": quota_text}}
             out["parity_vs_oracle"] = bool(par1 and parn)
         if saved_stdout is not None:
             sys.stdout.flush()

@@ -495,14 +495,16 @@ def test_1080p_pair_against_oracle(bbme, oracle):
     assert np.array_equal(got, exp) and np.array_equal(again, exp)
 
 
-def test_4k_uncorrelated_frames_against_oracle(bbme, oracle):
-    """BASELINE configs[2] geometry (4K, 16x16, +-32, 4 levels) on the worst content for the regulariser: two
-    unrelated noise frames, so that nearly every block changes in nearly every sweep (long queues, full work
-    lists, overflow list).  The oracle needs a few seconds here because its searches hit the image border early."""
-    rng = np.random.default_rng(5)
+@pytest.mark.parametrize("search_size,block_size,seed", [(80, 16, 5), (72, 8, 6)], ids=["cfg3_b16", "cfg4_b8"])
+def test_4k_uncorrelated_frames_against_oracle(bbme, oracle, search_size, block_size, seed):
+    """BASELINE configs[2] and configs[3] at full size (4K, 4 levels, +-32; 16x16 blocks, and 8x8 blocks = 130 560
+    level-0 macroblocks, motion_framework.cpp:226-244) on the worst content for the regulariser: two unrelated noise
+    frames, so that nearly every block changes in nearly every sweep (long queues, full work lists, overflow list).
+    The oracle needs 5-15 seconds here because its searches hit the image border early."""
+    rng = np.random.default_rng(seed)
     f1 = rng.integers(0, 256, (2160, 3840), dtype=np.uint8)
     f2 = rng.integers(0, 256, (2160, 3840), dtype=np.uint8)
-    search, block = [80] * 4, [16] * 4
+    search, block = [search_size] * 4, [block_size] * 4
     mf = bbme.MF(f1, f2, search, block, 4)
     got = mf.calcMotionBlockMatching()
     flag, _ = mf.last_sweep_passes()
