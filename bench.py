@@ -222,6 +222,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=8,
                     help="N=1 only: also report the throughput of a sequence with this many independent pairs in flight "
                          "(one context and stream per pair); 0 = skip.  Reported beside `value`, never as `value`")
+    ap.add_argument("--seq-batch", type=int, default=2, help="pairs per batched context in the `sequence` leg")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal on one GPU: run the N>1 code path (process group, gather, expand) with world size 1")
     args = ap.parse_args()
@@ -304,14 +305,20 @@ def main():
     # pairs of a sequence overlap well.  Reported as `sequence`, beside the single-pair `value`.
     sequence = None
     if rank == 0 and not use_dist and args.in_flight > 1:
-        ctxs = [mf]
-        for k in range(1, args.in_flight):
+        # Pairs that share a GPU go into BATCHED contexts (bbme_create_batch: every kernel works on all pairs of the context
+        # at once): the device dispatches the dependent kernels of many streams no faster than one per ~4 us chip-wide, so
+        # one context per pair is dispatch-bound (69 launches per pair); `--seq-batch` pairs per context, in_flight / batch
+        # contexts (streams) side by side so that one context's searches overlap the others' latency-bound sweeps.
+        per = max(1, min(args.seq_batch, args.in_flight))
+        n_ctx = max(1, args.in_flight // per)
+        frames = [(t1, t2)]
+        for k in range(1, n_ctx * per):
             g1, g2, _ = bbme.synth_pair(w, h, 1000 + 30 + k, max_motion=24)
-            ctxs.append(bbme.MF(torch.from_numpy(g1).cuda(), torch.from_numpy(g2).cuda(), [search] * levels,
-                                [block] * levels, levels, device=local_rank, frames_on_device=True))
+            frames.append((torch.from_numpy(g1).cuda(), torch.from_numpy(g2).cuda()))
+        ctxs = [bbme.MFBatch(frames[i * per:(i + 1) * per], [search] * levels, [block] * levels, levels, device=local_rank,
+                             frames_on_device=True) for i in range(n_ctx)]
         for c in ctxs:
             c.set_speculation(False)              # with pairs in flight the chip is busy anyway
-            c.set_relaxation(False)
             c.estimate_async()
         for c in ctxs:
             c.synchronize()
@@ -323,15 +330,16 @@ def main():
         for c in ctxs:
             c.synchronize()
         dt = time.perf_counter() - t0
-        same = bool(np.array_equal(mf.get_flow(), result_flow))
-        sequence = {"pairs_in_flight": len(ctxs), "value": round(blocks[0] * len(ctxs) * seq_steps / dt / 1e6, 4),
-                    "unit": "Mblocks/s", "ms_per_pair": round(dt / (seq_steps * len(ctxs)) * 1e3, 4),
-                    "pairs": seq_steps * len(ctxs), "first_pair_field_unchanged": same,
+        same = bool(np.array_equal(ctxs[0].get_pair_flow(0), result_flow))
+        n_pairs = n_ctx * per
+        sequence = {"pairs_in_flight": n_pairs, "contexts": n_ctx, "pairs_per_context": per,
+                    "value": round(blocks[0] * n_pairs * seq_steps / dt / 1e6, 4),
+                    "unit": "Mblocks/s", "ms_per_pair": round(dt / (seq_steps * n_pairs) * 1e3, 4),
+                    "pairs": seq_steps * n_pairs, "first_pair_field_unchanged": same,
                     "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}
-        for c in ctxs[1:]:
+        for c in ctxs:
             c.close()
-        mf.set_speculation(True)
-        mf.set_relaxation(True)
+        del frames
 
     # the boundary with host buffers (never `value`): frames in (pinned) host memory -> upload (2 x 8.3 MB at 4K), padding +
     # pyramid on the GPU, estimate, download of the dense field (66.8 MB) or of the compact 2x2-cell grid (4.2 MB)

@@ -68,6 +68,8 @@ SIGNATURES = {
     "bbme_search_plan_host_waves": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, _P(C.c_int), C.c_void_p, _P(C.c_int),
                                               _P(C.c_int)]),
     "bbme_create": (C.c_int, [_P(Params), C.c_int, C.c_int, C.c_int, _P(_ctx)]),
+    "bbme_create_batch": (C.c_int, [_P(Params), C.c_int, C.c_int, C.c_int, C.c_int, _P(_ctx)]),
+    "bbme_batch_size": (C.c_int, [_ctx, _P(C.c_int)]),
     "bbme_destroy": (C.c_int, [_ctx]),
     "bbme_set_stream": (C.c_int, [_ctx, C.c_void_p]),
     "bbme_get_stream": (C.c_int, [_ctx, _P(C.c_void_p)]),
@@ -75,6 +77,13 @@ SIGNATURES = {
     "bbme_level_geometry": (C.c_int, [_ctx, C.c_int] + [_P(C.c_int)] * 4),
     "bbme_set_frames_host": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int]),
     "bbme_set_frames_device": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int]),
+    "bbme_set_frames_host_pair": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "bbme_set_frames_host_async": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "bbme_set_frames_device_pair": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "bbme_flow_device_pair": (C.c_int, [_ctx, C.c_int, _P(C.c_void_p)]),
+    "bbme_get_flow_host_pair": (C.c_int, [_ctx, C.c_int, C.c_void_p]),
+    "bbme_cells_device_pair": (C.c_int, [_ctx, C.c_int, _P(C.c_void_p)]),
+    "bbme_get_cells_host_pair": (C.c_int, [_ctx, C.c_int, C.c_void_p]),
     "bbme_level_planes_device": (C.c_int, [_ctx, C.c_int, _P(C.c_void_p), _P(C.c_void_p)]),
     "bbme_set_level_planes_host": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p]),
     "bbme_get_level_planes_host": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p]),

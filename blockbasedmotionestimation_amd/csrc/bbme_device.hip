@@ -52,6 +52,11 @@ struct Level {
     bool split_pays = false;                          // the two-wave plan is at least 20 % shorter per wave
     int fast_pitch_dw = 0;
     size_t fast_lds_bytes = 0;
+    // batch: every per-pair buffer holds ctx->batch copies, pair p at p * stride elements (multiples of 64 elements)
+    uint32_t plane_stride = 0;                        // img1 / img2, bytes
+    uint32_t small_stride = 0;                        // small[], pred, fix_list: words
+    uint32_t big_stride = 0;                          // big[]: words
+    uint32_t grid_stride(const mv_t *g) const { return (g == small[0] || g == small[1]) ? small_stride : big_stride; }
 };
 
 }  // namespace
@@ -60,6 +65,10 @@ struct bbme_ctx {
     bbme_params params{};
     Geometry geom{};
     int device = 0;
+    int batch = 1;                                // independent frame pairs this context holds (blockIdx.y of every kernel)
+    size_t flow_stride = 0;                       // floats from pair to pair in `flow`
+    uint32_t list_stride = 0, own_stride = 0;     // words from pair to pair in list[] / own
+    size_t raw_stride = 0;                        // bytes from pair to pair in raw[]
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::vector<Level> lv;
@@ -76,7 +85,8 @@ struct bbme_ctx {
     uint32_t *own = nullptr;                      // ownership counters of the solver, one word per block
     uint32_t own_pitch = 0;                       // transposed layout: 32 residue classes of own_pitch words
     uint32_t *counters = nullptr;                 // 64 words (RegArgs::counters)
-    bool frames_set = false;
+    uint64_t frames_mask = 0;                     // bit p: pair p has frames (bbme_estimate needs every pair's)
+    bool frames_set() const { return frames_mask == (batch >= 64 ? ~0ull : (1ull << batch) - 1ull); }
     double *epe_scratch = nullptr;                // partial sums + counts of bbme_calculate_mse_device (allocated on first use)
     int solve_waves = 4;                          // waves per solver workgroup (1, 2 or 4); BBME_SOLVE_WAVES
     int solve_wgs = 128;                          // most workgroups of k_reg_solve (4 independent waves each): one wave per SIMD
@@ -123,14 +133,17 @@ void drop_graph(bbme_ctx *c)
 // that path the solver's ownership words and counters are stale too: cleared, so that the context stays usable.
 int check_converged(bbme_ctx *c)
 {
-    uint32_t flag = 0;
-    HIP_TRY(hipMemcpyAsync(&flag, c->counters + 5, sizeof flag, hipMemcpyDeviceToHost, c->stream));
+    std::vector<uint32_t> flags((size_t)c->batch, 0u);    // counters[5] of every pair (64 words apart)
+    HIP_TRY(hipMemcpy2DAsync(flags.data(), sizeof(uint32_t), c->counters + 5, 64 * sizeof(uint32_t), sizeof(uint32_t),
+                             (size_t)c->batch, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    bool flag = false;
+    for (uint32_t f : flags) flag = flag || f != 0;
     if (!flag) return BBME_OK;
-    HIP_TRY(hipMemsetAsync(c->own, 0, (size_t)c->own_pitch * 32 * 4, c->stream));
-    HIP_TRY(hipMemsetAsync(c->counters, 0, 256, c->stream));
-    HIP_TRY(hipMemsetAsync(c->flags[0], 0, c->flag_bytes, c->stream));
-    HIP_TRY(hipMemsetAsync(c->flags[1], 0, c->flag_bytes, c->stream));
+    HIP_TRY(hipMemsetAsync(c->own, 0, (size_t)c->own_stride * 4 * c->batch, c->stream));
+    HIP_TRY(hipMemsetAsync(c->counters, 0, (size_t)256 * c->batch, c->stream));
+    HIP_TRY(hipMemsetAsync(c->flags[0], 0, c->flag_bytes * c->batch, c->stream));
+    HIP_TRY(hipMemsetAsync(c->flags[1], 0, c->flag_bytes * c->batch, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return bbme::fail(BBME_ERR_STATE, "a regulariser sweep hit its round cap without converging: the motion field is not "
                                       "the reference's and has been discarded");
@@ -139,9 +152,9 @@ int check_converged(bbme_ctx *c)
 // ---- launches ---------------------------------------------------------------------------
 
 template <int B>
-void launch_search_t(const SearchArgs &a, int nblocks, size_t lds, hipStream_t s)
+void launch_search_t(const SearchArgs &a, int nblocks, int batch, size_t lds, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_search_generic<B>, dim3(nblocks), dim3(64), lds, s, a);
+    hipLaunchKernelGGL(k_search_generic<B>, dim3(nblocks, batch), dim3(64), lds, s, a);
 }
 
 // Where the search of `level` takes its predictions from (copyMVs, :828-843), by mode:
@@ -154,6 +167,7 @@ int set_prediction_source(bbme_ctx *c, int level, int mode, Args &a)
     a.mode = mode;
     a.pred = L.pred;
     a.coarse = nullptr;
+    a.s_plane = L.plane_stride; a.s_pred = L.small_stride; a.s_out = L.small_stride; a.s_coarse = 0;
     if (level + 1 >= (int)c->lv.size()) return BBME_OK;
     Level &C = c->lv[level + 1];
     a.coarse_block = C.block;
@@ -170,6 +184,7 @@ int set_prediction_source(bbme_ctx *c, int level, int mode, Args &a)
         a.coarse_cell_shift = 1;
     }
     a.coarse_cols = C.width >> a.coarse_cell_shift;
+    a.s_coarse = C.grid_stride(a.coarse);
     return BBME_OK;
 }
 
@@ -194,33 +209,35 @@ int launch_search_fast(bbme_ctx *c, int level, int mode, hipStream_t stream, siz
     const int grid = c->xcd_remap ? ((nblocks + 7) / 8) * 8 : nblocks;
     const size_t lds = std::max(L.fast_lds_bytes, lds_floor);
     a.fix_count = L.fix_count;
+    a.s_fix_list = L.small_stride;
+    const unsigned P = (unsigned)c->batch;
     // a level with fewer macroblocks than the chip has SIMDs: one wave per block leaves most SIMDs idle and every busy one
     // with a single wave, so the launch lasts as long as one block does -- two waves share each block then
     if (mode == kSearchPlain && L.tasks2 && nblocks <= c->split_blocks && (L.split_pays || c->split_forced)) {
         a.tasks = L.tasks2; a.rounds = L.rounds2; a.nrounds = L.nrounds2;
-        if (L.block == 16) hipLaunchKernelGGL((k_search_fast<16, 2>), dim3(grid), dim3(128), lds, stream, a);
-        else if (L.block == 32) hipLaunchKernelGGL((k_search_fast<32, 2>), dim3(grid), dim3(128), lds, stream, a);
-        else hipLaunchKernelGGL((k_search_fast<8, 2>), dim3(grid), dim3(128), lds, stream, a);
+        if (L.block == 16) hipLaunchKernelGGL((k_search_fast<16, 2>), dim3(grid, P), dim3(128), lds, stream, a);
+        else if (L.block == 32) hipLaunchKernelGGL((k_search_fast<32, 2>), dim3(grid, P), dim3(128), lds, stream, a);
+        else hipLaunchKernelGGL((k_search_fast<8, 2>), dim3(grid, P), dim3(128), lds, stream, a);
         HIP_TRY(hipGetLastError());
         return BBME_OK;
     }
     if (mode == kSearchFixup && a.coarse) {
         // list the blocks whose prediction changed, then search those (k_fixup_list, k_search_list)
         a.mode = kSearchPlain;
-        hipLaunchKernelGGL(k_fixup_list, dim3((nblocks + 255) / 256), dim3(256), 0, stream, a, L.block, L.fix_count, L.fix_list);
+        hipLaunchKernelGGL(k_fixup_list, dim3((nblocks + 255) / 256, P), dim3(256), 0, stream, a, L.block, L.fix_count, L.fix_list);
         const int lgrid = std::max(64, nblocks / 4);
-        if (L.block == 16) hipLaunchKernelGGL(k_search_list<16>, dim3(lgrid), dim3(64), lds, stream, a, L.fix_count, L.fix_list);
-        else if (L.block == 32) hipLaunchKernelGGL(k_search_list<32>, dim3(lgrid), dim3(64), lds, stream, a, L.fix_count, L.fix_list);
-        else hipLaunchKernelGGL(k_search_list<8>, dim3(lgrid), dim3(64), lds, stream, a, L.fix_count, L.fix_list);
+        if (L.block == 16) hipLaunchKernelGGL(k_search_list<16>, dim3(lgrid, P), dim3(64), lds, stream, a, L.fix_count, L.fix_list);
+        else if (L.block == 32) hipLaunchKernelGGL(k_search_list<32>, dim3(lgrid, P), dim3(64), lds, stream, a, L.fix_count, L.fix_list);
+        else hipLaunchKernelGGL(k_search_list<8>, dim3(lgrid, P), dim3(64), lds, stream, a, L.fix_count, L.fix_list);
         HIP_TRY(hipGetLastError());
         return BBME_OK;
     }
     if (L.block == 16)
-        hipLaunchKernelGGL((k_search_fast<16, 1>), dim3(grid), dim3(64), lds, stream, a);
+        hipLaunchKernelGGL((k_search_fast<16, 1>), dim3(grid, P), dim3(64), lds, stream, a);
     else if (L.block == 32)
-        hipLaunchKernelGGL((k_search_fast<32, 1>), dim3(grid), dim3(64), lds, stream, a);
+        hipLaunchKernelGGL((k_search_fast<32, 1>), dim3(grid, P), dim3(64), lds, stream, a);
     else
-        hipLaunchKernelGGL((k_search_fast<8, 1>), dim3(grid), dim3(64), lds, stream, a);
+        hipLaunchKernelGGL((k_search_fast<8, 1>), dim3(grid, P), dim3(64), lds, stream, a);
     HIP_TRY(hipGetLastError());
     return BBME_OK;
 }
@@ -245,11 +262,11 @@ int launch_search(bbme_ctx *c, int level, int mode = kSearchPlain, hipStream_t s
         const int nblocks = (L.width / L.block) * (L.height / L.block);
         const size_t lds = std::max(L.lds_bytes, lds_floor);
         switch (L.block) {
-        case 4:  launch_search_t<4>(a, nblocks, lds, stream); break;
-        case 8:  launch_search_t<8>(a, nblocks, lds, stream); break;
-        case 16: launch_search_t<16>(a, nblocks, lds, stream); break;
-        case 32: launch_search_t<32>(a, nblocks, lds, stream); break;
-        case 64: launch_search_t<64>(a, nblocks, lds, stream); break;
+        case 4:  launch_search_t<4>(a, nblocks, c->batch, lds, stream); break;
+        case 8:  launch_search_t<8>(a, nblocks, c->batch, lds, stream); break;
+        case 16: launch_search_t<16>(a, nblocks, c->batch, lds, stream); break;
+        case 32: launch_search_t<32>(a, nblocks, c->batch, lds, stream); break;
+        case 64: launch_search_t<64>(a, nblocks, c->batch, lds, stream); break;
         default: return bbme::fail(BBME_ERR_UNSUPPORTED, "block size %d", L.block);
         }
         HIP_TRY(hipGetLastError());
@@ -261,7 +278,7 @@ int launch_search(bbme_ctx *c, int level, int mode = kSearchPlain, hipStream_t s
 
 template <int BS>
 void launch_sweep_t(RegArgs a, uint8_t *const flags[2], int relax_steps, int max_solve_wgs, int solve_waves, bool jacobi,
-                    long long lanes_max, long long fine_max, hipStream_t s)
+                    long long lanes_max, long long fine_max, unsigned P, hipStream_t s)
 {
     constexpr int LPB = RegCfg<BS>::LPB;
     const long long blocks = (long long)a.rows * a.cols;
@@ -274,9 +291,9 @@ void launch_sweep_t(RegArgs a, uint8_t *const flags[2], int relax_steps, int max
     // chip from ~32 000 blocks on, and it still wins up to four times that: 1.815 -> 1.78 ms per cfg3 pair; slower from 500 000)
     auto pass1 = [&]() {
         if (BS <= 16 && blocks <= lanes_max)               // (b >= 32: a lane would walk 32+ rows -- 13 against 6 us at b = 32)
-            hipLaunchKernelGGL(k_reg_pass1_lanes<BS>, dim3((unsigned)((blocks * 16 + 255) / 256)), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(k_reg_pass1_lanes<BS>, dim3((unsigned)((blocks * 16 + 255) / 256), P), dim3(256), 0, s, a);
         else
-            hipLaunchKernelGGL(k_reg_pass1<BS>, dim3(grid1), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(k_reg_pass1<BS>, dim3(grid1, P), dim3(256), 0, s, a);
     };
     if (jacobi) {
         // opt-in, NOT the reference's field: every block against the field as the previous sweep left it, and no more
@@ -291,12 +308,12 @@ void launch_sweep_t(RegArgs a, uint8_t *const flags[2], int relax_steps, int max
         a.flag_cur = flags[cur]; a.flag_next = flags[cur ^ 1];
         constexpr int T = RegIter<BS>::T;
         const unsigned tiles = (unsigned)(((a.cols + T - 1) / T) * ((a.rows + T - 1) / T));
-        hipLaunchKernelGGL(k_reg_iter<BS>, dim3(tiles), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_reg_iter<BS>, dim3(tiles, P), dim3(256), 0, s, a);
     }
     a.flag_cur = flags[cur]; a.flag_next = nullptr;
     // small grids: scan segments of 4 flags, so that the stale blocks of a row are dealt to four times as many waves
-    if (blocks <= fine_max) hipLaunchKernelGGL((k_reg_solve<BS, 4>), dim3(grid2), dim3(64 * solve_waves), 0, s, a);
-    else hipLaunchKernelGGL((k_reg_solve<BS, 16>), dim3(grid2), dim3(64 * solve_waves), 0, s, a);
+    if (blocks <= fine_max) hipLaunchKernelGGL((k_reg_solve<BS, 4>), dim3(grid2, P), dim3(64 * solve_waves), 0, s, a);
+    else hipLaunchKernelGGL((k_reg_solve<BS, 16>), dim3(grid2, P), dim3(64 * solve_waves), 0, s, a);
 }
 
 int launch_sweep(bbme_ctx *c, int level, int b, int mult)
@@ -326,6 +343,8 @@ int launch_sweep(bbme_ctx *c, int level, int b, int mult)
     a.list0 = c->list[0]; a.list1 = c->list[1];
     a.own = c->own;
     a.own_pitch = c->own_pitch;
+    a.s_plane = L.plane_stride; a.s_old = L.grid_stride(a.old_grid); a.s_est = L.grid_stride(a.est);
+    a.s_list = c->list_stride; a.s_own = c->own_stride; a.s_flag = (uint32_t)c->flag_bytes;
     static const int rounds_env = getenv("BBME_LOCAL_ROUNDS") ? atoi(getenv("BBME_LOCAL_ROUNDS")) : 8;
     a.local_rounds = std::max(1, rounds_env);
     static const int wide_env = getenv("BBME_WIDE_THRESHOLD") ? atoi(getenv("BBME_WIDE_THRESHOLD")) : 16;
@@ -351,12 +370,12 @@ int launch_sweep(bbme_ctx *c, int level, int b, int mult)
         steps = (c->relax && nblk >= min_blocks && b <= max_b) ? (mult == 1 ? s1 : s2) : 0;
     }
     switch (b) {
-    case 2:  launch_sweep_t<2>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->stream); break;
-    case 4:  launch_sweep_t<4>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->stream); break;
-    case 8:  launch_sweep_t<8>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->stream); break;
-    case 16: launch_sweep_t<16>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->stream); break;
-    case 32: launch_sweep_t<32>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->stream); break;
-    case 64: launch_sweep_t<64>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->stream); break;
+    case 2:  launch_sweep_t<2>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, (unsigned)c->batch, c->stream); break;
+    case 4:  launch_sweep_t<4>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, (unsigned)c->batch, c->stream); break;
+    case 8:  launch_sweep_t<8>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, (unsigned)c->batch, c->stream); break;
+    case 16: launch_sweep_t<16>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, (unsigned)c->batch, c->stream); break;
+    case 32: launch_sweep_t<32>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, (unsigned)c->batch, c->stream); break;
+    case 64: launch_sweep_t<64>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, (unsigned)c->batch, c->stream); break;
     default: return bbme::fail(BBME_ERR_UNSUPPORTED, "block size %d", b);
     }
     HIP_TRY(hipGetLastError());
@@ -371,8 +390,8 @@ int launch_expand(bbme_ctx *c)
     if (L.cur_block != 2) return bbme::fail(BBME_ERR_STATE, "level 0 has not been regularised down to 2x2 blocks");
     const int cc = L.width / 2, cr = L.height / 2;
     const long long threads = (long long)cc * cr * 2;
-    hipLaunchKernelGGL(k_expand, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream,
-                       L.cur_grid, cc, cr, c->flow, L.width);
+    hipLaunchKernelGGL(k_expand, dim3((unsigned)((threads + 255) / 256), (unsigned)c->batch), dim3(256), 0, c->stream,
+                       L.cur_grid, cc, cr, c->flow, L.width, L.grid_stride(L.cur_grid), c->flow_stride);
     HIP_TRY(hipGetLastError());
     return BBME_OK;
 }
@@ -474,8 +493,14 @@ extern "C" {
 
 int bbme_create(const bbme_params *params, int width, int height, int device, bbme_ctx **out)
 {
+    return bbme_create_batch(params, width, height, device, 1, out);
+}
+
+int bbme_create_batch(const bbme_params *params, int width, int height, int device, int pairs, bbme_ctx **out)
+{
     if (!params || !out) return bbme::fail(BBME_ERR_INVALID, "bbme_create: null argument");
     *out = nullptr;
+    if (pairs < 1 || pairs > BBME_MAX_BATCH) return bbme::fail(BBME_ERR_INVALID, "batch of %d pairs (1..%d)", pairs, BBME_MAX_BATCH);
     if (int rc = validate_params(*params)) return rc;
     Geometry g;
     if (int rc = plan_padding(width, height, *params, g)) return rc;
@@ -497,6 +522,9 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
 
     bbme_ctx *c = new bbme_ctx();
     c->params = *params; c->geom = g; c->device = device;
+    c->batch = pairs;
+    const size_t P = (size_t)pairs;
+    auto round64 = [](size_t n) { return (n + 63) / 64 * 64; };
     if (const char *e = getenv("BBME_SOLVE_WGS")) c->solve_wgs = std::max(1, std::min(8192, atoi(e)));
     if (const char *e = getenv("BBME_RELAX_STEPS")) c->relax_steps = std::max(0, std::min(64, atoi(e)));
     if (const char *e = getenv("BBME_SOLVE_WAVES")) { const int v = atoi(e); c->solve_waves = v <= 1 ? 1 : (v == 2 ? 2 : 4); }
@@ -533,24 +561,25 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
         L.range = sp.range; L.ncand = (int)sp.dx.size();
         L.pitch_dw = (L.block + 2 * L.range) / 4 + 2;
         L.lds_bytes = ((size_t)(L.block + 2 * L.range) * L.pitch_dw + (size_t)L.block * L.block / 4) * 4;
-        const size_t plane = (size_t)L.width * L.height + 64;          // slack: row_sad may touch 3 bytes past the end
-        const size_t cells = (size_t)(L.width / 2) * (L.height / 2);
-        const size_t own_blocks = (size_t)(L.width / L.block) * (L.height / L.block);
+        const size_t plane = round64((size_t)L.width * L.height + 64) + 192;   // slack: row_sad may touch 3 bytes past the end
+        const size_t cells = round64((size_t)(L.width / 2) * (L.height / 2));
+        const size_t own_blocks = round64((size_t)(L.width / L.block) * (L.height / L.block));
+        L.plane_stride = (uint32_t)plane; L.small_stride = (uint32_t)own_blocks; L.big_stride = (uint32_t)cells;
         max_blocks = std::max(max_blocks, cells);
         std::vector<uint32_t> packed(sp.dx.size());
         for (size_t i = 0; i < sp.dx.size(); ++i)
             packed[i] = ((uint32_t)(uint16_t)sp.dx[i]) | ((uint32_t)(uint16_t)sp.dy[i] << 16);
-        if ((err = hipMalloc(&L.img1, plane)) != hipSuccess || (err = hipMalloc(&L.img2, plane)) != hipSuccess ||
-            (err = hipMalloc(&L.small[0], own_blocks * sizeof(mv_t))) != hipSuccess ||
-            (err = hipMalloc(&L.small[1], own_blocks * sizeof(mv_t))) != hipSuccess ||
-            (err = hipMalloc(&L.pred, own_blocks * sizeof(mv_t))) != hipSuccess ||
-            (err = hipMalloc(&L.fix_list, own_blocks * sizeof(uint32_t))) != hipSuccess ||
-            (err = hipMalloc(&L.fix_count, 64)) != hipSuccess ||
-            (err = hipMemset(L.fix_count, 0, 64)) != hipSuccess ||
-            (err = hipMalloc(&L.big[0], cells * sizeof(mv_t))) != hipSuccess ||
-            (err = hipMalloc(&L.big[1], cells * sizeof(mv_t))) != hipSuccess ||
+        if ((err = hipMalloc(&L.img1, P * plane)) != hipSuccess || (err = hipMalloc(&L.img2, P * plane)) != hipSuccess ||
+            (err = hipMalloc(&L.small[0], P * own_blocks * sizeof(mv_t))) != hipSuccess ||
+            (err = hipMalloc(&L.small[1], P * own_blocks * sizeof(mv_t))) != hipSuccess ||
+            (err = hipMalloc(&L.pred, P * own_blocks * sizeof(mv_t))) != hipSuccess ||
+            (err = hipMalloc(&L.fix_list, P * own_blocks * sizeof(uint32_t))) != hipSuccess ||
+            (err = hipMalloc(&L.fix_count, P * 64)) != hipSuccess ||
+            (err = hipMemset(L.fix_count, 0, P * 64)) != hipSuccess ||
+            (err = hipMalloc(&L.big[0], P * cells * sizeof(mv_t))) != hipSuccess ||
+            (err = hipMalloc(&L.big[1], P * cells * sizeof(mv_t))) != hipSuccess ||
             (err = hipMalloc(&L.spiral, packed.size() * 4)) != hipSuccess ||
-            (err = hipMemset(L.img1, 0, plane)) != hipSuccess || (err = hipMemset(L.img2, 0, plane)) != hipSuccess ||
+            (err = hipMemset(L.img1, 0, P * plane)) != hipSuccess || (err = hipMemset(L.img2, 0, P * plane)) != hipSuccess ||
             (err = hipMemcpy(L.spiral, packed.data(), packed.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
             return cleanup_fail(bbme::fail(BBME_ERR_HIP, "allocating level %d: %s", l, hipGetErrorString(err)));
         if (L.block == 8 || L.block == 16 || L.block == 32) {
@@ -587,18 +616,20 @@ int bbme_create(const bbme_params *params, int width, int height, int device, bb
     c->own_pitch = (uint32_t)(((max_blocks + 31) / 32 + 63) / 64 * 64 + 33);
     const size_t bit_words = (size_t)c->own_pitch * 32;
     c->flag_bytes = (max_blocks + 2047) / 2048 * 2048 + 2048;             // whole 16-flag segments (k_reg_solve), zero beyond the grid
-    const size_t flow_bytes = (size_t)g.padded_width * g.padded_height * 2 * sizeof(float);
+    c->flow_stride = (size_t)g.padded_width * g.padded_height * 2;        // floats
+    c->list_stride = (uint32_t)max_blocks; c->own_stride = (uint32_t)bit_words;
+    const size_t flow_bytes = P * c->flow_stride * sizeof(float);
     if ((err = hipMalloc(&c->flow, flow_bytes)) != hipSuccess ||
-        (err = hipMalloc(&c->list[0], max_blocks * 4)) != hipSuccess ||
-        (err = hipMalloc(&c->list[1], max_blocks * 4)) != hipSuccess ||
-        (err = hipMalloc(&c->flags[0], c->flag_bytes)) != hipSuccess ||
-        (err = hipMalloc(&c->flags[1], c->flag_bytes)) != hipSuccess ||
-        (err = hipMemset(c->flags[0], 0, c->flag_bytes)) != hipSuccess ||
-        (err = hipMemset(c->flags[1], 0, c->flag_bytes)) != hipSuccess ||
-        (err = hipMalloc(&c->own, bit_words * 4)) != hipSuccess ||
-        (err = hipMalloc(&c->counters, 256)) != hipSuccess ||
-        (err = hipMemset(c->own, 0, bit_words * 4)) != hipSuccess ||
-        (err = hipMemset(c->counters, 0, 256)) != hipSuccess ||
+        (err = hipMalloc(&c->list[0], P * max_blocks * 4)) != hipSuccess ||
+        (err = hipMalloc(&c->list[1], P * max_blocks * 4)) != hipSuccess ||
+        (err = hipMalloc(&c->flags[0], P * c->flag_bytes)) != hipSuccess ||
+        (err = hipMalloc(&c->flags[1], P * c->flag_bytes)) != hipSuccess ||
+        (err = hipMemset(c->flags[0], 0, P * c->flag_bytes)) != hipSuccess ||
+        (err = hipMemset(c->flags[1], 0, P * c->flag_bytes)) != hipSuccess ||
+        (err = hipMalloc(&c->own, P * bit_words * 4)) != hipSuccess ||
+        (err = hipMalloc(&c->counters, P * 256)) != hipSuccess ||
+        (err = hipMemset(c->own, 0, P * bit_words * 4)) != hipSuccess ||
+        (err = hipMemset(c->counters, 0, P * 256)) != hipSuccess ||
         (err = hipMemset(c->flow, 0, flow_bytes)) != hipSuccess)
         return cleanup_fail(bbme::fail(BBME_ERR_HIP, "allocating work buffers: %s", hipGetErrorString(err)));
     HIP_TRY(hipDeviceSynchronize());
@@ -741,38 +772,61 @@ int bbme_level_geometry(const bbme_ctx *c, int level, int *w, int *h, int *b, in
 
 int bbme_set_frames_host(bbme_ctx *c, const uint8_t *image1, const uint8_t *image2, int pitch)
 {
+    if (int rc = bbme_set_frames_host_async(c, 0, image1, image2, pitch)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));        // the caller may re-use its buffers
+    return BBME_OK;
+}
+
+int bbme_set_frames_host_pair(bbme_ctx *c, int pair, const uint8_t *image1, const uint8_t *image2, int pitch)
+{
+    if (int rc = bbme_set_frames_host_async(c, pair, image1, image2, pitch)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BBME_OK;
+}
+
+int bbme_set_frames_host_async(bbme_ctx *c, int pair, const uint8_t *image1, const uint8_t *image2, int pitch)
+{
     if (int rc = check_ctx(c)) return rc;
-    if (!image1 || !image2 || pitch < c->geom.width) return bbme::fail(BBME_ERR_INVALID, "bbme_set_frames_host: bad arguments");
+    if (!image1 || !image2 || pitch < c->geom.width || pair < 0 || pair >= c->batch)
+        return bbme::fail(BBME_ERR_INVALID, "bbme_set_frames_host: bad arguments");
     HIP_TRY(hipSetDevice(c->device));
     // the frames as they are go to HBM; zero border and pyrDown cascade run there (bbme_set_frames_device) -- the same
     // integers as bbme_pad_zero_host / bbme_pyr_down_host produce, without 18 ms of single-threaded host filtering at 4K
     const Geometry &g = c->geom;
     const size_t bytes = (size_t)g.width * g.height;
+    c->raw_stride = (bytes + 64 + 255) / 256 * 256;
     const uint8_t *src[2] = {image1, image2};
     for (int i = 0; i < 2; ++i) {
-        if (!c->raw[i]) HIP_TRY(hipMalloc(&c->raw[i], bytes + 64));
-        HIP_TRY(hipMemcpy2DAsync(c->raw[i], g.width, src[i], pitch, g.width, g.height, hipMemcpyHostToDevice, c->stream));
+        if (!c->raw[i]) HIP_TRY(hipMalloc(&c->raw[i], c->raw_stride * c->batch));
+        HIP_TRY(hipMemcpy2DAsync(c->raw[i] + pair * c->raw_stride, g.width, src[i], pitch, g.width, g.height, hipMemcpyHostToDevice, c->stream));
     }
-    if (int rc = bbme_set_frames_device(c, c->raw[0], c->raw[1], g.width)) return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));        // the caller may re-use its buffers
-    return BBME_OK;
+    // no host wait: with pinned source buffers the upload, the border, the pyramid and an estimate behind them overlap whatever
+    // the host does next; the buffers must stay untouched until the context's stream has passed this point
+    return bbme_set_frames_device_pair(c, pair, c->raw[0] + pair * c->raw_stride, c->raw[1] + pair * c->raw_stride, g.width);
 }
 
 int bbme_set_frames_device(bbme_ctx *c, const uint8_t *d_image1, const uint8_t *d_image2, int pitch)
 {
+    return bbme_set_frames_device_pair(c, 0, d_image1, d_image2, pitch);
+}
+
+int bbme_set_frames_device_pair(bbme_ctx *c, int pair, const uint8_t *d_image1, const uint8_t *d_image2, int pitch)
+{
     if (int rc = check_ctx(c)) return rc;
-    if (!d_image1 || !d_image2 || pitch < c->geom.width) return bbme::fail(BBME_ERR_INVALID, "bbme_set_frames_device: bad arguments");
+    if (!d_image1 || !d_image2 || pitch < c->geom.width || pair < 0 || pair >= c->batch)
+        return bbme::fail(BBME_ERR_INVALID, "bbme_set_frames_device: bad arguments");
     HIP_TRY(hipSetDevice(c->device));
     const Geometry &g = c->geom;
+    const size_t pp_ = (size_t)pair;
     // both frames per launch: zero border into the level-0 planes, then the pyrDown cascade
     Level &L0 = c->lv[0];
-    PlanePair pp{{d_image1, d_image2}, {L0.img1, L0.img2}};
+    PlanePair pp{{d_image1, d_image2}, {L0.img1 + pp_ * L0.plane_stride, L0.img2 + pp_ * L0.plane_stride}};
     const long long chunks = (long long)((L0.width + 15) / 16) * L0.height;
     hipLaunchKernelGGL(k_pad_zero, dim3((unsigned)((chunks + 255) / 256), 2), dim3(256), 0, c->stream,
                        pp, g.width, g.height, pitch, g.pad_x, g.pad_y, L0.width, L0.height);
     for (size_t l = 1; l < c->lv.size(); ++l) {
         Level &P = c->lv[l - 1], &L = c->lv[l];
-        PlanePair q{{P.img1, P.img2}, {L.img1, L.img2}};
+        PlanePair q{{P.img1 + pp_ * P.plane_stride, P.img2 + pp_ * P.plane_stride}, {L.img1 + pp_ * L.plane_stride, L.img2 + pp_ * L.plane_stride}};
         if (P.width % 8 == 0) {
             const long long n = (long long)(L.width / 4) * L.height;
             hipLaunchKernelGGL(k_pyr_down4, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, c->stream, q, P.width, P.height);
@@ -782,7 +836,7 @@ int bbme_set_frames_device(bbme_ctx *c, const uint8_t *d_image1, const uint8_t *
         }
     }
     HIP_TRY(hipGetLastError());
-    c->frames_set = true;
+    c->frames_mask |= 1ull << pair;
     return BBME_OK;
 }
 
@@ -791,7 +845,7 @@ int bbme_level_planes_device(bbme_ctx *c, int level, uint8_t **d1, uint8_t **d2)
     if (int rc = check_level(c, level)) return rc;
     if (d1) *d1 = c->lv[level].img1;
     if (d2) *d2 = c->lv[level].img2;
-    c->frames_set = true;          // the caller fills them in place
+    c->frames_mask |= 1ull;        // the caller fills them in place (pair 0)
     return BBME_OK;
 }
 
@@ -804,7 +858,7 @@ int bbme_set_level_planes_host(bbme_ctx *c, int level, const uint8_t *image1, co
     HIP_TRY(hipMemcpyAsync(L.img1, image1, (size_t)L.width * L.height, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(L.img2, image2, (size_t)L.width * L.height, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->frames_set = true;
+    c->frames_mask |= 1ull;
     return BBME_OK;
 }
 
@@ -822,7 +876,7 @@ int bbme_get_level_planes_host(bbme_ctx *c, int level, uint8_t *image1, uint8_t 
 int bbme_estimate(bbme_ctx *c)
 {
     if (int rc = check_ctx(c)) return rc;
-    if (!c->frames_set) return bbme::fail(BBME_ERR_STATE, "bbme_estimate: no frames set");
+    if (!c->frames_set()) return bbme::fail(BBME_ERR_STATE, "bbme_estimate: no frames set (every pair of a batch needs its frames)");
     HIP_TRY(hipSetDevice(c->device));
     if (c->profiling) return profiled_pyramid(c);
     if (!c->use_graph) return enqueue_pyramid(c, c->speculate);
@@ -852,42 +906,65 @@ int bbme_synchronize(bbme_ctx *c)
     return check_converged(c);
 }
 
-int bbme_flow_device(bbme_ctx *c, const float **d_flow)
+int bbme_batch_size(const bbme_ctx *c, int *pairs)
 {
     if (int rc = check_ctx(c)) return rc;
-    if (!d_flow) return bbme::fail(BBME_ERR_INVALID, "null output");
-    *d_flow = c->flow;
+    if (!pairs) return bbme::fail(BBME_ERR_INVALID, "null output");
+    *pairs = c->batch;
     return BBME_OK;
 }
 
-int bbme_get_flow_host(bbme_ctx *c, float *flow)
+static int check_pair(const bbme_ctx *c, int pair)
 {
     if (int rc = check_ctx(c)) return rc;
+    if (pair < 0 || pair >= c->batch) return bbme::fail(BBME_ERR_INVALID, "pair %d of a batch of %d", pair, c->batch);
+    return BBME_OK;
+}
+
+int bbme_flow_device(bbme_ctx *c, const float **d_flow) { return bbme_flow_device_pair(c, 0, d_flow); }
+
+int bbme_flow_device_pair(bbme_ctx *c, int pair, const float **d_flow)
+{
+    if (int rc = check_pair(c, pair)) return rc;
+    if (!d_flow) return bbme::fail(BBME_ERR_INVALID, "null output");
+    *d_flow = c->flow + (size_t)pair * c->flow_stride;
+    return BBME_OK;
+}
+
+int bbme_get_flow_host(bbme_ctx *c, float *flow) { return bbme_get_flow_host_pair(c, 0, flow); }
+
+int bbme_get_flow_host_pair(bbme_ctx *c, int pair, float *flow)
+{
+    if (int rc = check_pair(c, pair)) return rc;
     if (!flow) return bbme::fail(BBME_ERR_INVALID, "null output");
     HIP_TRY(hipSetDevice(c->device));
-    const size_t bytes = (size_t)c->geom.padded_width * c->geom.padded_height * 2 * sizeof(float);
-    HIP_TRY(hipMemcpyAsync(flow, c->flow, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(flow, c->flow + (size_t)pair * c->flow_stride, c->flow_stride * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     return check_converged(c);
 }
 
-int bbme_get_cells_host(bbme_ctx *c, int16_t *cells)
+int bbme_get_cells_host(bbme_ctx *c, int16_t *cells) { return bbme_get_cells_host_pair(c, 0, cells); }
+
+int bbme_get_cells_host_pair(bbme_ctx *c, int pair, int16_t *cells)
 {
-    if (int rc = check_ctx(c)) return rc;
+    if (int rc = check_pair(c, pair)) return rc;
     if (!cells) return bbme::fail(BBME_ERR_INVALID, "null output");
     Level &L = c->lv[0];
     if (L.cur_block != 2) return bbme::fail(BBME_ERR_STATE, "level 0 is not at 2x2 cells");
     HIP_TRY(hipSetDevice(c->device));
     const size_t n = (size_t)(L.width / 2) * (L.height / 2);
-    HIP_TRY(hipMemcpyAsync(cells, L.cur_grid, n * sizeof(mv_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(cells, L.cur_grid + (size_t)pair * L.grid_stride(L.cur_grid), n * sizeof(mv_t), hipMemcpyDeviceToHost, c->stream));
     return check_converged(c);
 }
 
-int bbme_cells_device(bbme_ctx *c, const int16_t **d_cells)
+int bbme_cells_device(bbme_ctx *c, const int16_t **d_cells) { return bbme_cells_device_pair(c, 0, d_cells); }
+
+int bbme_cells_device_pair(bbme_ctx *c, int pair, const int16_t **d_cells)
 {
-    if (int rc = check_ctx(c)) return rc;
+    if (int rc = check_pair(c, pair)) return rc;
     if (!d_cells) return bbme::fail(BBME_ERR_INVALID, "null output");
     // two sweeps per block size always leave the final field of a level in the same buffer (Level::final_grid)
-    *d_cells = reinterpret_cast<const int16_t *>(c->lv[0].final_grid());
+    const Level &L = c->lv[0];
+    *d_cells = reinterpret_cast<const int16_t *>(L.final_grid() + (size_t)pair * L.grid_stride(L.final_grid()));
     return BBME_OK;
 }
 
@@ -906,7 +983,7 @@ int bbme_expand_cells_device_on(bbme_ctx *c, const int16_t *d_cells, float *d_fl
     const long long threads = (long long)cc * cr * 2;
     hipLaunchKernelGGL(k_expand, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                        hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream,
-                       reinterpret_cast<const mv_t *>(d_cells), cc, cr, d_flow, L.width);
+                       reinterpret_cast<const mv_t *>(d_cells), cc, cr, d_flow, L.width, 0u, (size_t)0);
     HIP_TRY(hipGetLastError());
     return BBME_OK;
 }
@@ -947,7 +1024,7 @@ int bbme_calculate_mse_device(bbme_ctx *c, const float *d_gtruth, int gt_width, 
 int bbme_stage_search(bbme_ctx *c, int level)
 {
     if (int rc = check_level(c, level)) return rc;
-    if (!c->frames_set) return bbme::fail(BBME_ERR_STATE, "no frames set");
+    if (!c->frames_set()) return bbme::fail(BBME_ERR_STATE, "no frames set");
     HIP_TRY(hipSetDevice(c->device));
     return launch_search(c, level);
 }
@@ -955,7 +1032,7 @@ int bbme_stage_search(bbme_ctx *c, int level)
 int bbme_stage_regularize(bbme_ctx *c, int level, int block, int mult)
 {
     if (int rc = check_level(c, level)) return rc;
-    if (!c->frames_set) return bbme::fail(BBME_ERR_STATE, "no frames set");
+    if (!c->frames_set()) return bbme::fail(BBME_ERR_STATE, "no frames set");
     HIP_TRY(hipSetDevice(c->device));
     return launch_sweep(c, level, block, mult);
 }

@@ -47,7 +47,16 @@ struct SearchArgs {
     mv_t *out;                  // (H/B) x (W/B)
     int cols;                   // W / B
     int pitch_dw;               // LDS window pitch in dwords
+    // batch: a context may hold several independent frame pairs (blockIdx.y = pair); every per-pair buffer of pair p starts
+    // p * stride elements after pair 0's (shift_pair, first statement of every kernel)
+    uint32_t s_plane, s_coarse, s_pred, s_out;
 };
+__device__ __forceinline__ void shift_pair(SearchArgs &a, uint32_t p)
+{
+    a.image1 += (size_t)p * a.s_plane; a.image2 += (size_t)p * a.s_plane;
+    if (a.coarse) a.coarse += (size_t)p * a.s_coarse;
+    a.pred += (size_t)p * a.s_pred; a.out += (size_t)p * a.s_out;
+}
 
 // copyMVs (:828-843) as the search kernels see it: the MV of the coarse block covering pixel (i, j) of this level.
 // A block's search result depends on its prediction alone, which is what makes the search of level l speculable:
@@ -75,6 +84,7 @@ template <int B>
 __global__ __launch_bounds__(64) void k_search_generic(SearchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    shift_pair(a, blockIdx.y);
     constexpr int BW = B / 4;
     const int lane = threadIdx.x;
     const int bc = blockIdx.x % a.cols, br = blockIdx.x / a.cols;
@@ -220,7 +230,15 @@ struct FastSearchArgs {
     int pitch_dw;               // LDS window pitch in dwords (odd)
     int nblocks;                // macroblocks of the level
     int xcd_remap;              // 1 = XCD-aware block order
+    uint32_t s_plane, s_coarse, s_pred, s_out, s_fix_list;   // element strides from pair to pair (see SearchArgs); fix_count: 16 words
 };
+__device__ __forceinline__ void shift_pair(FastSearchArgs &a, uint32_t p)
+{
+    a.image1 += (size_t)p * a.s_plane; a.image2 += (size_t)p * a.s_plane;
+    if (a.coarse) a.coarse += (size_t)p * a.s_coarse;
+    a.pred += (size_t)p * a.s_pred; a.out += (size_t)p * a.s_out;
+    a.fix_count += (size_t)p * 16u;
+}
 
 // Current block operand: B <= 16 keeps the whole block in SGPRs; B = 32 keeps its address, and search_strip brings the block
 // through the SGPRs eight rows at a time.
@@ -506,6 +524,7 @@ template <int B, int W>
 __global__ __launch_bounds__(64 * W) void k_search_fast(FastSearchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    shift_pair(a, blockIdx.y);
     // Workgroups are dealt round-robin over the 8 XCDs, each with a private L2.  Give every XCD a
     // contiguous eighth of the raster so that neighbouring macroblocks -- whose windows overlap by
     // 80 % -- meet in the same L2.  Pure speed: any placement gives the same result.
@@ -525,6 +544,9 @@ __global__ __launch_bounds__(64 * W) void k_search_fast(FastSearchArgs a)
 __global__ __launch_bounds__(256) void k_fixup_list(FastSearchArgs a, int block, uint32_t *count, uint32_t *list)
 {
     __shared__ uint32_t s_n, s_base;
+    shift_pair(a, blockIdx.y);
+    count = a.fix_count;
+    list += (size_t)blockIdx.y * a.s_fix_list;
     const uint32_t bid = blockIdx.x * 256 + threadIdx.x;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
@@ -547,7 +569,9 @@ template <int B>
 __global__ __launch_bounds__(64) void k_search_list(FastSearchArgs a, const uint32_t *count, const uint32_t *list)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const uint32_t n = *count;
+    shift_pair(a, blockIdx.y);
+    list += (size_t)blockIdx.y * a.s_fix_list;
+    const uint32_t n = *a.fix_count;
     for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {               // wave-uniform
         const uint32_t bid = list[e];
         mv_t m;
@@ -598,7 +622,19 @@ struct RegArgs {
     uint32_t *counters;         // [0..2] overflow list lengths (rotating), [3] safety-net passes, [4] blocks re-evaluated,
                                 // [5] sticky: a sweep hit a cap without converging, [6] solver ticket, [7] most rounds of
                                 // one wave, [8] rounds summed, [9..15] phase profile
+    // batch (blockIdx.y = pair): element strides from pair to pair of the per-pair buffers; counters: 64 words
+    uint32_t s_plane, s_old, s_est, s_list, s_own, s_flag;
 };
+__device__ __forceinline__ void shift_pair(RegArgs &a, uint32_t p)
+{
+    a.image1 += (size_t)p * a.s_plane; a.image2 += (size_t)p * a.s_plane;
+    a.old_grid += (size_t)p * a.s_old; a.est += (size_t)p * a.s_est;
+    a.list0 += (size_t)p * a.s_list; a.list1 += (size_t)p * a.s_list;
+    a.own += (size_t)p * a.s_own;
+    if (a.flag_cur) a.flag_cur += (size_t)p * a.s_flag;
+    if (a.flag_next) a.flag_next += (size_t)p * a.s_flag;
+    a.counters += (size_t)p * 64u;
+}
 
 template <int BS> struct RegCfg {
     static constexpr int LPB = BS >= 4 ? (BS > 64 ? 64 : BS) : 1;   // lanes per block
@@ -1006,6 +1042,7 @@ __global__ __launch_bounds__(256) void k_reg_pass1(RegArgs a)
 {
     constexpr int LPB = RegCfg<BS>::LPB;
     __builtin_amdgcn_s_setprio(2);                 // latency-bound: ahead of a speculative search sharing the SIMD
+    shift_pair(a, blockIdx.y);
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     // the solver's counters (nothing else touches them before this sweep's solver launch)
     if (t < 16 && t != 5) a.counters[t] = 0;
@@ -1070,6 +1107,7 @@ template <int BS>
 __global__ __launch_bounds__(256) void k_reg_pass1_lanes(RegArgs a)
 {
     __builtin_amdgcn_s_setprio(2);
+    shift_pair(a, blockIdx.y);
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t < 16 && t != 5) a.counters[t] = 0;                  // as k_reg_pass1
     const long long g = t >> 4;
@@ -1101,6 +1139,7 @@ __global__ __launch_bounds__(256) void k_reg_iter(RegArgs a)
     __shared__ uint32_t n_list[2];
     __shared__ uint32_t queued[(T * T + 31) / 32];
     __builtin_amdgcn_s_setprio(2);
+    shift_pair(a, blockIdx.y);
     const int t = threadIdx.x;
     const int tiles_x = (a.cols + T - 1) / T;
     const int r0 = ((int)blockIdx.x / tiles_x) * T, c0 = ((int)blockIdx.x % tiles_x) * T;
@@ -1280,6 +1319,7 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
     __shared__ uint32_t qmem[4][QCAP];
     __shared__ uint32_t s_ticket;
     __builtin_amdgcn_s_setprio(2);
+    shift_pair(a, blockIdx.y);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint32_t *q = qmem[wave];
@@ -1472,8 +1512,10 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
 // every pixel of level 0 takes the MV of its 2x2 cell, as float2.  One thread per cell row pair.
 // =======================================================================================
 __global__ __launch_bounds__(256) void k_expand(const mv_t *cells, int cell_cols, int cell_rows,
-                                                float *flow, int width)
+                                                float *flow, int width, uint32_t s_cells, size_t s_flow)
 {
+    cells += (size_t)blockIdx.y * s_cells;                            // batch: blockIdx.y = pair
+    flow += (size_t)blockIdx.y * s_flow;
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long total = (long long)cell_cols * cell_rows * 2;     // two pixel rows per cell row
     if (t >= total) return;

@@ -233,6 +233,76 @@ class MF:
                         [x.value for x in v]))
 
 
+class MFBatch(MF):
+    """Several independent frame pairs of one size behind ONE launch sequence (bbme_create_batch): the pairs of a sequence
+    that share a GPU.  Every kernel of the estimate works on all pairs at once; each pair's field is bit for bit what an MF
+    of its own returns.  `pairs` = [(image1, image2), ...] host arrays, or torch uint8 CUDA tensors with
+    frames_on_device=True.  Methods inherited from MF without a pair index address pair 0."""
+
+    def __init__(self, pairs, search_size, block_size, num_levels=None, device=0, frames_on_device=False):
+        if num_levels is None:
+            num_levels = len(block_size)
+        if num_levels <= 0 or not pairs:
+            raise _capi.BbmeError(_capi.ERR_INVALID, "num_levels must be > 0 and pairs non-empty")
+        self._ctx = C.c_void_p()
+        self._lib = _capi.lib()
+        self.device = device
+        self.batch = len(pairs)
+        self._torch_frames = [None] * self.batch
+        h, w = pairs[0][0].shape
+        self.orig_height, self.orig_width = h, w
+        self.params = _capi.make_params(list(search_size)[:num_levels], list(block_size)[:num_levels])
+        _capi.check(self._lib.bbme_create_batch(C.byref(self.params), w, h, device, self.batch, C.byref(self._ctx)))
+        pw, ph, px, py = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _capi.check(self._lib.bbme_get_geometry(self._ctx, C.byref(pw), C.byref(ph), C.byref(px), C.byref(py)))
+        self.padded_width, self.padded_height = pw.value, ph.value
+        self.padding_x, self.padding_y = px.value, py.value
+        self.num_levels = num_levels
+        for p, (image1, image2) in enumerate(pairs):
+            if frames_on_device:
+                self.set_pair_device(p, image1, image2)
+            else:
+                self.set_pair(p, image1, image2)
+
+    def set_pair(self, pair, image1, image2):
+        image1 = np.ascontiguousarray(image1, dtype=np.uint8)
+        image2 = np.ascontiguousarray(image2, dtype=np.uint8)
+        if image1.shape != (self.orig_height, self.orig_width) or image2.shape != image1.shape:
+            raise _capi.BbmeError(_capi.ERR_INVALID, "frames must keep the size the context was created for")
+        _capi.check(self._lib.bbme_set_frames_host_pair(self._ctx, pair, image1.ctypes.data, image2.ctypes.data, self.orig_width))
+
+    def set_pair_device(self, pair, image1, image2):
+        assert image1.is_cuda and image2.is_cuda and image1.dtype.itemsize == 1
+        assert image1.stride(1) == 1 and image2.stride(1) == 1 and image1.stride(0) == image2.stride(0)
+        self._torch_frames[pair] = (image1, image2)
+        import torch
+        _capi.check(self._lib.bbme_wait_for_stream(self._ctx, C.c_void_p(torch.cuda.current_stream(image1.device).cuda_stream)))
+        _capi.check(self._lib.bbme_set_frames_device_pair(self._ctx, pair, image1.data_ptr(), image2.data_ptr(), image1.stride(0)))
+
+    def get_pair_flow(self, pair, out=None):
+        shape = (self.padded_height, self.padded_width, 2)
+        if out is None:
+            out = np.empty(shape, np.float32)
+        elif out.shape != shape or out.dtype != np.float32 or not out.flags.c_contiguous:
+            raise _capi.BbmeError(_capi.ERR_INVALID, "get_pair_flow: out must be a C-contiguous float32 array of shape %s" % (shape,))
+        _capi.check(self._lib.bbme_get_flow_host_pair(self._ctx, pair, out.ctypes.data))
+        return out
+
+    def get_pair_cells(self, pair, out=None):
+        shape = (self.padded_height // 2, self.padded_width // 2, 2)
+        if out is None:
+            out = np.empty(shape, np.int16)
+        elif out.shape != shape or out.dtype != np.int16 or not out.flags.c_contiguous:
+            raise _capi.BbmeError(_capi.ERR_INVALID, "get_pair_cells: out must be a C-contiguous int16 array of shape %s" % (shape,))
+        _capi.check(self._lib.bbme_get_cells_host_pair(self._ctx, pair, out.ctypes.data))
+        return out
+
+    def calcMotionBlockMatching(self):
+        """Every pair's dense padded field, in order."""
+        self.estimate_async()
+        return [self.get_pair_flow(p) for p in range(self.batch)]
+
+
 def plan_padding(width, height, search_size, block_size):
     """padded_width, padded_height, padding_x, padding_y of MF::MF (motion_framework.cpp:14-54)."""
     p = _capi.make_params(search_size, block_size)

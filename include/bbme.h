@@ -25,6 +25,7 @@ extern "C" {
 #endif
 
 #define BBME_MAX_LEVELS 8
+#define BBME_MAX_BATCH 64
 
 typedef enum {
     BBME_OK = 0,
@@ -124,6 +125,15 @@ int bbme_search_plan_host_waves(int range, int block_size, int waves, uint32_t *
 /* Allocates every device buffer for a (width x height) frame pair: padded planes of
  * all levels, MV grids, work lists, the dense output.  device = HIP ordinal. */
 int bbme_create(const bbme_params *params, int width, int height, int device, bbme_ctx **out);
+/* A context for `pairs` (1..BBME_MAX_BATCH) independent frame pairs of one size: `pairs` MF objects behind one launch
+ * sequence.  The reference holds all state of a pair in one MF object and carries nothing from pair to pair
+ * (motion_framework.h:37-46), so the pairs of a sequence can be estimated side by side: every kernel of bbme_estimate then
+ * works on all pairs at once (one more grid dimension), which is how a sequence keeps one GPU busy -- the regulariser of a
+ * single pair is a chain of short dependent launches that leaves most of the chip idle, and the device dispatches dependent
+ * kernels of many streams no faster than one per few microseconds.  Each pair's field is bit for bit what a context of its
+ * own would produce.  Entry points without a pair index address pair 0. */
+int bbme_create_batch(const bbme_params *params, int width, int height, int device, int pairs, bbme_ctx **out);
+int bbme_batch_size(const bbme_ctx *ctx, int *pairs);
 int bbme_destroy(bbme_ctx *ctx);
 /* hipStream_t to run on (default: a stream the ctx creates).  Pass the raw handle. */
 int bbme_set_stream(bbme_ctx *ctx, void *hip_stream);
@@ -136,12 +146,19 @@ int bbme_level_geometry(const bbme_ctx *ctx, int level, int *width, int *height,
 
 /* ---- inputs ------------------------------------------------------------------------- */
 
-/* MF::MF(image1, image2, ...) (motion_framework.cpp:4-111) for host images: pads with
- * zeros, builds the pyramid with pyrDown on the host, uploads all planes. */
+/* MF::MF(image1, image2, ...) (motion_framework.cpp:4-111) for host images: uploads the two frames as they are and runs
+ * the zero border (:57-61) and the pyrDown cascade (:86-106) as HIP kernels on the ctx stream, exactly as
+ * bbme_set_frames_device does; returns when the upload has completed (the caller may re-use its buffers). */
 int bbme_set_frames_host(bbme_ctx *ctx, const uint8_t *image1, const uint8_t *image2, int pitch);
+int bbme_set_frames_host_pair(bbme_ctx *ctx, int pair, const uint8_t *image1, const uint8_t *image2, int pitch);
+/* The same without the host wait: upload, border and pyramid are only enqueued on the ctx stream (truly asynchronous when
+ * the source buffers are pinned: hipHostMalloc / hipHostRegister).  The buffers must stay untouched until the ctx stream
+ * has passed this point (bbme_synchronize, or an event the caller records on bbme_get_stream's stream). */
+int bbme_set_frames_host_async(bbme_ctx *ctx, int pair, const uint8_t *image1, const uint8_t *image2, int pitch);
 /* Same constructor for frames already resident in HBM (unpadded, width x height):
  * zero padding and the whole pyrDown cascade run as HIP kernels on the ctx stream. */
 int bbme_set_frames_device(bbme_ctx *ctx, const uint8_t *d_image1, const uint8_t *d_image2, int pitch);
+int bbme_set_frames_device_pair(bbme_ctx *ctx, int pair, const uint8_t *d_image1, const uint8_t *d_image2, int pitch);
 /* Which of the reference's two block searches MF::calcLevelBM calls (motion_framework.cpp:235-236): the spiral full
  * search find_min_block_spiral (:296-422, the live one: ties go to the candidate visited first on the spiral; a
  * prediction outside the image gives a zero MV) or the raster full search find_min_block (:246-294, commented out in the
@@ -189,10 +206,13 @@ int bbme_synchronize(bbme_ctx *ctx);
 /* The cv::Mat returned by calcMotionBlockMatching (:218): dense padded H0 x W0
  * float2 (u,v) = (dx,dy), device pointer, pitch == padded width. */
 int bbme_flow_device(bbme_ctx *ctx, const float **d_flow);
+int bbme_flow_device_pair(bbme_ctx *ctx, int pair, const float **d_flow);
 /* Synchronises, then copies the dense padded field to the host. */
 int bbme_get_flow_host(bbme_ctx *ctx, float *flow /* padded_h * padded_w * 2 */);
+int bbme_get_flow_host_pair(bbme_ctx *ctx, int pair, float *flow);
 /* Compact result: one int16 (dx,dy) pair per 2x2 cell of level 0 ((H0/2) x (W0/2)). */
 int bbme_cells_device(bbme_ctx *ctx, const int16_t **d_cells);
+int bbme_cells_device_pair(bbme_ctx *ctx, int pair, const int16_t **d_cells);
 /* copy_to_all_pixels (:815-826) for a cell grid that lives anywhere in HBM (e.g. gathered from
  * another GPU): writes the dense padded H0 x W0 float2 field to d_flow, on the ctx stream. */
 int bbme_expand_cells_device(bbme_ctx *ctx, const int16_t *d_cells, float *d_flow);
@@ -200,6 +220,7 @@ int bbme_expand_cells_device(bbme_ctx *ctx, const int16_t *d_cells, float *d_flo
  * so that the expansion of one step's results overlaps the next step's estimate. */
 int bbme_expand_cells_device_on(bbme_ctx *ctx, const int16_t *d_cells, float *d_flow, void *hip_stream);
 int bbme_get_cells_host(bbme_ctx *ctx, int16_t *cells);
+int bbme_get_cells_host_pair(bbme_ctx *ctx, int pair, int16_t *cells);
 /* Flow::CalculateMSE (rw_flow.cpp:309-332) on the device, fused with the driver's subsampling
  * (main_class.cpp:58-70): mean end-point error between a ground-truth field in HBM (gt_width x gt_height,
  * u,v interleaved) and the context's current result taken at every `scale`-th pixel of the unpadded frame and

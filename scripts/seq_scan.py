@@ -59,10 +59,26 @@ for mode, jac, spec, relax in (("exact", False, False, False), ("exact+relax", F
         ms = run(ctxs[:p], a.steps)
         line.append("P=%d %.3f" % (p, ms))
     print("%-18s ms/pair: %s" % (mode, "  ".join(line)), flush=True)
+# the same pairs as batched contexts (bbme_create_batch): n contexts x b pairs each
 for c in ctxs:
-    c.set_regularizer_mode(False)
-    c.set_speculation(False)
-    c.set_relaxation(False)
+    c.close()
+ctxs = []
+frames = [bbme.synth_pair(w, h, 1030 + k, max_motion=24)[:2] for k in range(16)]
+for total in (8, 16):
+    for b in (1, 2, 4, 8, 16):
+        if b > total:
+            continue
+        bs = [bbme.MFBatch(frames[i * b:(i + 1) * b], [search] * levels, [block] * levels, levels) for i in range(total // b)]
+        for spec, relax in ((False, False), (False, True), (True, True)):
+            for c in bs:
+                c.set_speculation(spec)
+                c.set_relaxation(relax)
+            ms = run(bs, max(3, a.steps // 2)) / b
+            print("batched: %2d pairs as %2d contexts x %2d pairs, spec %d relax %d: %.3f ms/pair  (%.1f Mblocks/s)" %
+                  (total, total // b, b, spec, relax, ms, blocks0 / ms / 1e3), flush=True)
+        for c in bs:
+            c.close()
+sys.exit(0)
 for stag in (100e-6, 200e-6, 400e-6):
     print("exact, P=8, stagger %3.0f us: %.3f ms/pair" % (stag * 1e6, run(ctxs[:8], a.steps, stag)), flush=True)
 for c in ctxs:

@@ -541,6 +541,39 @@ def test_pipelined_sequence_matches_oracle_per_pair(bbme, oracle):
     mf.close()
 
 
+@pytest.mark.parametrize("w,h,search,block,levels", [(328, 200, 40, 8, 3), (400, 304, 48, 16, 2), (712, 488, 80, 16, 3)])
+def test_batched_context_matches_the_oracle_pair_by_pair(bbme, oracle, w, h, search, block, levels):
+    """bbme_create_batch: several pairs behind one launch sequence (every kernel gets the pair as a second grid dimension,
+    every per-pair buffer a pair stride).  Each pair's field must be the oracle's -- the pairs share nothing
+    (motion_framework.h:37-46) -- with the speculative search on (the default) and off, after replacing one pair's frames,
+    and the compact cells must agree with the dense fields."""
+    ss, bs = [search] * levels, [block] * levels
+    pairs = [bbme.synth_pair(w, h, 5100 + i, max_motion=9 + 2 * i)[:2] for i in range(5)]
+
+    def expect(f1, f2):
+        omf = oracle.OracleMF(f1, f2, ss, bs)
+        out = omf.calc_motion_block_matching()
+        omf.close()
+        return out
+    exp = [expect(f1, f2) for f1, f2 in pairs]
+    mb = bbme.MFBatch(pairs[:4], ss, bs, levels)
+    assert mb.batch == 4
+    for spec in (True, False):
+        mb.set_speculation(spec)
+        got = mb.calcMotionBlockMatching()
+        for p in range(4):
+            assert np.array_equal(got[p], exp[p]), "pair %d (speculation %s)" % (p, spec)
+            cells = mb.get_pair_cells(p)
+            assert np.array_equal(np.repeat(np.repeat(cells, 2, 0), 2, 1).astype(np.float32), got[p])
+    mb.set_pair(2, *pairs[4])                                   # a new pair into slot 2; the others keep their frames
+    got = mb.calcMotionBlockMatching()
+    for p, e in enumerate([exp[0], exp[1], exp[4], exp[3]]):
+        assert np.array_equal(got[p], e), "pair %d after replacing pair 2" % p
+    with pytest.raises(bbme.BbmeError):
+        mb.get_pair_flow(4)
+    mb.close()
+
+
 @pytest.mark.parametrize("cfg", ["cfg2_1080p", "cfg3_4k", "cfg4_4k_b8"])
 def test_full_size_properties(bbme, cfg):
     """BASELINE.json's full sizes, through properties that need no oracle run:
