@@ -589,7 +589,8 @@ int bbme_create_batch(const bbme_params *params, int width, int height, int devi
             L.rank_pitch = sp.rank_pitch;
             L.nrounds = (int)plan.rounds.size();
             L.fast_pitch_dw = plan.pitch_dw;
-            L.fast_lds_bytes = (size_t)(L.block + 2 * L.range) * plan.pitch_dw * 4;   // the window; the block is in SGPRs
+            // the window (+ for B <= 16 a copy of the block, 16-byte aligned, for the rim rounds of the tight plan)
+            L.fast_lds_bytes = (((size_t)(L.block + 2 * L.range) * plan.pitch_dw + 3) & ~(size_t)3) * 4 + (size_t)L.block * L.block;
             if ((err = hipMalloc(&L.rank_of, sp.rank_of.size() * 2 + 64)) != hipSuccess ||
                 (err = hipMalloc(&L.tasks, plan.tasks.size() * 4)) != hipSuccess ||
                 (err = hipMalloc(&L.rounds, plan.rounds.size() * 4)) != hipSuccess ||
@@ -602,7 +603,11 @@ int bbme_create_batch(const bbme_params *params, int width, int height, int devi
             L.nrounds2 = (int)plan2.rounds.size();
             // a round of strips of S rows walks S + B - 1 window rows: the split only pays where it shortens a wave's walk
             // (+-32 at B <= 16: 0.6x; +-16: the square is too small to fill 128 lanes with tall strips, 0.94-1.0x -- measured slower)
-            auto walk = [&](const SearchPlan &p) { int w = 0; for (uint32_t S : p.rounds) w += (int)S + L.block - 1; return w; };
+            auto walk = [&](const SearchPlan &p) {
+                int w = 0;
+                for (uint32_t code : p.rounds) w += (code >> 8) ? L.block / 4 : (int)(code & 0xffu) + L.block - 1;   // rim rounds are short
+                return w;
+            };
             L.split_pays = 5 * walk(plan2) <= 4 * walk(plan);
             if (plan2.pitch_dw != plan.pitch_dw) return cleanup_fail(bbme::fail(BBME_ERR_STATE, "search plans disagree on the window pitch"));
             if ((err = hipMalloc(&L.tasks2, plan2.tasks.size() * 4)) != hipSuccess ||

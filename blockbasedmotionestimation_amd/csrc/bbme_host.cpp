@@ -235,7 +235,15 @@ SearchPlan plan_search(int range, int block_size, int max_strip, int lanes)
     const int n = 2 * range + 1;
     p.groups = (n + 3) / 4;
     p.pitch_dw = (p.groups + block_size / 4) | 1;
-    std::vector<int> next(p.groups, 0);                      // first uncovered candidate row per column group
+    // n = 4 G' + 1 (every even range): the last column group would hold ONE candidate column and three of padding, and
+    // the last candidate row a strip of height one in every group -- 9 % of the QSADs of a +-32 search.  The tight plan
+    // packs the G' x (n - 1) rectangle into strips and gives the rim its own rounds (kernel: search_row_parts,
+    // search_aligned_column): kind 1, candidate row n - 1 of the G' full groups, four lanes per (group, row), a quarter of
+    // the block's rows each; kind 2, candidate column n - 1 (dx = +R, dword aligned in the staged window: R is even),
+    // one candidate per lane, v_sad_u8.  rounds[] = S | kind << 8.
+    const bool tight = n % 4 == 1 && n >= 9 && block_size <= 16 && !getenv("BBME_LOOSE_PLAN");
+    const int groups_main = tight ? p.groups - 1 : p.groups, rows_main = tight ? n - 1 : n;
+    std::vector<int> next(groups_main, 0);                   // first uncovered candidate row per column group
     auto emit_round = [&](int s, int want) {
         p.rounds.push_back((uint32_t)s);
         std::vector<uint32_t> t;
@@ -243,8 +251,8 @@ SearchPlan plan_search(int range, int block_size, int max_strip, int lanes)
         bool more = true;
         while (more && (int)t.size() < want) {
             more = false;
-            for (int g = 0; g < p.groups && (int)t.size() < want; ++g)
-                if (n - next[g] >= s) {
+            for (int g = 0; g < groups_main && (int)t.size() < want; ++g)
+                if (rows_main - next[g] >= s) {
                     t.push_back((uint32_t)g | ((uint32_t)next[g] << 8));
                     next[g] += s;
                     more = true;
@@ -256,14 +264,30 @@ SearchPlan plan_search(int range, int block_size, int max_strip, int lanes)
     for (int s = max_strip; s >= 1; s >>= 1) {
         for (;;) {
             int avail = 0;
-            for (int g = 0; g < p.groups; ++g) avail += (n - next[g]) / s;
+            for (int g = 0; g < groups_main; ++g) avail += (rows_main - next[g]) / s;
             if (avail >= lanes) emit_round(s, lanes);
             else break;
         }
     }
     int left = 0;
-    for (int g = 0; g < p.groups; ++g) left += n - next[g];
+    for (int g = 0; g < groups_main; ++g) left += rows_main - next[g];
     while (left > 0) { emit_round(1, std::min(left, lanes)); left -= std::min(left, lanes); }
+    if (tight) {
+        auto emit_tasks = [&](uint32_t kind, const std::vector<uint32_t> &all) {
+            for (size_t i = 0; i < all.size(); i += (size_t)lanes) {
+                p.rounds.push_back(1u | kind << 8);
+                for (int k = 0; k < lanes; ++k)
+                    p.tasks.push_back(i + k < all.size() ? all[i + k] : 0xffffffffu);
+            }
+        };
+        std::vector<uint32_t> parts, column;
+        for (int g = 0; g < groups_main; ++g)
+            for (uint32_t part = 0; part < 4; ++part)       // the four lanes of a quad share one (group, row)
+                parts.push_back((uint32_t)g | (uint32_t)(n - 1) << 8 | part << 16);
+        for (int dy = 0; dy < n; ++dy) column.push_back((uint32_t)dy);
+        emit_tasks(1u, parts);
+        emit_tasks(2u, column);
+    }
     return p;
 }
 

@@ -24,6 +24,15 @@ __device__ __forceinline__ mv_t mv_pack(int x, int y) { return ((uint32_t)x & 0x
 // 16 bytes at any byte address (gfx950 global loads need no alignment; bbme_selftest_isa checks it)
 struct __attribute__((packed, aligned(1))) ua_u128 { uint32_t v[4]; };
 
+// DPP move within a row of 16 lanes (CTRL: quad_perm 0x00-0xff, row_mirror 0x140, row_half_mirror 0x141,
+// row_newbcast:n 0x150+n).  All 16 lanes of a row must be active.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_row(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true);
+}
+
+
 // =======================================================================================
 // K1 (generic form): MF::copyMVs + MF::calcLevelBM + MF::find_min_block_spiral
 // (motion_framework.cpp:828-843, 226-244, 296-422).  One wavefront per macroblock.
@@ -394,6 +403,83 @@ __device__ __forceinline__ uint32_t search_strip(const uint32_t *win, int P, con
     return best;
 }
 
+// The rim of the candidate square in the tight plan (plan_search, n = 2R + 1 = 4 G' + 1), B <= 16.
+// Kind 1: candidate row `dyi` of a full column group, four lanes of a quad per (group, row), lane `part` takes a quarter of the
+// block's rows -- the block operand differs from lane to lane, so it comes from the copy of the block in LDS (cur_lds), not
+// from the SGPRs -- and the four packed partial sums meet by two DPP quad moves (u16 halves cannot carry: totals stay below
+// 255 * B * B < 2^16).  Every lane of the wave calls it (DPP needs whole rows of 16 lanes active); idle lanes and parts
+// 1..3 leave `best` alone.
+template <int B>
+__device__ __forceinline__ uint32_t search_row_parts(const uint32_t *win, const uint32_t *cur_lds, int P, uint32_t task,
+                                                     const FastSearchArgs &a, uint32_t best, bool border,
+                                                     int xlo, int xhi, int ylo, int yhi)
+{
+    constexpr int BW = B / 4, RP = B / 4;                      // dwords per block row, block rows per part
+    struct __attribute__((packed, aligned(4))) pair_w { unsigned long long v; };
+    const bool idle = task == 0xffffffffu;
+    const int g = idle ? 0 : (int)(task & 0xffu);
+    const int dyi = idle ? 0 : (int)((task >> 8) & 0xffu);
+    const int part = idle ? 0 : (int)((task >> 16) & 3u);
+    const uint32_t *wrow = win + (dyi + part * RP) * P + g;
+    const uint32_t *crow = cur_lds + part * RP * BW;
+    unsigned long long acc = 0;
+#pragma unroll
+    for (int r = 0; r < RP; ++r) {
+#pragma unroll
+        for (int q = 0; q < BW; ++q)
+            acc = __builtin_amdgcn_qsad_pk_u16_u8(reinterpret_cast<const pair_w *>(wrow + q)->v, crow[r * BW + q], acc);
+        wrow += P;
+    }
+    uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);
+    lo += dpp_row<0xB1>(lo); hi += dpp_row<0xB1>(hi);           // partner in the pair
+    lo += dpp_row<0x4E>(lo); hi += dpp_row<0x4E>(hi);           // the other pair of the quad
+    if (idle || part != 0) return best;
+    const uint2 r4 = *reinterpret_cast<const uint2 *>(a.rank_of + (size_t)dyi * a.rank_pitch + 4 * g);
+    if (border) {
+        if (dyi < ylo || dyi > yhi) return best;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int dxi = 4 * g + c;
+            if (dxi < xlo || dxi > xhi) { if (c < 2) lo |= 0xffffu << (16 * c); else hi |= 0xffffu << (16 * (c - 2)); }
+        }
+    }
+    const uint32_t k0 = __builtin_amdgcn_perm(lo, r4.x, 0x05040100u);
+    const uint32_t k1 = __builtin_amdgcn_perm(lo, r4.x, 0x07060302u);
+    const uint32_t k2 = __builtin_amdgcn_perm(hi, r4.y, 0x05040100u);
+    const uint32_t k3 = __builtin_amdgcn_perm(hi, r4.y, 0x07060302u);
+    return min(best, min(min(k0, k1), min(k2, k3)));
+}
+
+// Kind 2: candidate column dx = +R, one candidate (row `dyi`) per lane.  Its window bytes start on a dword (the staged window
+// starts at dx = -R on a dword and 2R is a multiple of 4), so the plain v_sad_u8 applies: block dword from the SGPRs, window
+// dword from LDS, four absolute differences per lane-instruction at four times the QSAD's issue rate -- the same cost per
+// candidate as a QSAD column group with four live columns, instead of one live column in four.
+template <int B>
+__device__ __forceinline__ uint32_t search_aligned_column(const uint32_t *win, int P, const CurBlock<B> &cur, uint32_t task,
+                                                          const FastSearchArgs &a, uint32_t best, bool border,
+                                                          int xlo, int xhi, int ylo, int yhi)
+{
+    constexpr int BW = B / 4;
+    const bool idle = task == 0xffffffffu;
+    const int dyi = idle ? 0 : (int)(task & 0xffu);
+    const int dxi = 2 * a.range;
+    const uint32_t *wrow = win + dyi * P + (dxi >> 2);
+    uint32_t s0 = 0, s1 = 0;                                   // two chains: a v_sad_u8 result feeds the next one
+#pragma unroll
+    for (int r = 0; r < B; ++r) {
+#pragma unroll
+        for (int q = 0; q < BW; ++q) {
+            if ((r + q) & 1) s1 = __builtin_amdgcn_sad_u8(wrow[q], cur.at(r, q), s1);
+            else s0 = __builtin_amdgcn_sad_u8(wrow[q], cur.at(r, q), s0);
+        }
+        wrow += P;
+    }
+    const bool bad = idle || (border && (dxi < xlo || dxi > xhi || dyi < ylo || dyi > yhi));
+    const uint32_t rank = a.rank_of[(size_t)dyi * a.rank_pitch + dxi];
+    const uint32_t key = bad ? 0xffffffffu : (((s0 + s1) << 16) | rank);
+    return min(best, key);
+}
+
 // The search of macroblock `bid` from the coarse MV `m` (one wave; smem = the workgroup's dynamic LDS).
 // W waves share the macroblock (W = 2 on levels too small to give every SIMD two waves): they stage the window together,
 // each keeps the block in its own SGPRs, wave w takes tasks [64 w, 64 w + 64) of every round, and the W minima meet in LDS.
@@ -486,6 +572,12 @@ __device__ __forceinline__ void search_block_fast(const FastSearchArgs &a, uint3
             }
         }
     }
+    // B <= 16: a copy of the block behind the window in LDS, for the rounds whose lanes need different block rows (search_row_parts)
+    uint32_t *cur_lds = smem + ((wrows * P + 3) & ~3);
+    if constexpr (B <= 16) {
+        if (tid < B * BW)
+            cur_lds[tid] = *reinterpret_cast<const uint32_t *>(a.image1 + (size_t)(i + tid / BW) * a.width + j + 4 * (tid % BW));
+    }
     __syncthreads();
 
     // candidate (dxi, dyi) in [0, 2R]^2 is valid iff its block lies inside the image (:335)
@@ -495,8 +587,16 @@ __device__ __forceinline__ void search_block_fast(const FastSearchArgs &a, uint3
 
     uint32_t best = 0xffffffffu;
     for (int rd = 0; rd < a.nrounds; ++rd) {
-        const uint32_t S = a.rounds[rd];
+        const uint32_t code = a.rounds[rd];                 // strip height S | kind << 8 (plan_search)
+        const uint32_t S = code & 0xffu;
         const uint32_t task = a.tasks[rd * T + tid];
+        if (code >> 8) {
+            if constexpr (B <= 16) {
+                if ((code >> 8) == 1u) best = search_row_parts<B>(smem, cur_lds, P, task, a, best, border, xlo, xhi, ylo, yhi);
+                else best = search_aligned_column<B>(smem, P, cur, task, a, best, border, xlo, xhi, ylo, yhi);
+            }
+            continue;
+        }
         switch (S) {
         case 16: if constexpr (B <= 16) { best = search_strip<B, 16>(smem, P, cur, task, a, best, border, xlo, xhi, ylo, yhi); } break;
         case 8:  best = search_strip<B, 8>(smem, P, cur, task, a, best, border, xlo, xhi, ylo, yhi); break;
@@ -654,14 +754,6 @@ __device__ __forceinline__ mv_t load_est(const mv_t *p)
         return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else
         return *p;
-}
-
-// DPP move within a row of 16 lanes (CTRL: quad_perm 0x00-0xff, row_mirror 0x140, row_half_mirror 0x141,
-// row_newbcast:n 0x150+n).  All 16 lanes of a row must be active.
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp_row(uint32_t x)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true);
 }
 
 // Score the (up to nine) candidates of block (bx, by) and return the winner: find_min_candidate,

@@ -319,22 +319,44 @@ def test_search_plan_covers_every_candidate_once(bbme, rng, block, waves):
     n = 2 * rng + 1
     assert groups.value == (n + 3) // 4 and 1 <= nr.value <= cap
     assert pitch.value % 2 == 1 and pitch.value >= groups.value + block // 4
-    covered = np.zeros((groups.value, n), np.int32)
+    # every candidate (dx index, dy index) of the (2R+1)^2 square exactly once.  rounds[] = S | kind << 8: kind 0 strips of a
+    # column group (four candidate columns x S rows); kind 1 one candidate row of a group by the four lanes of a quad, a
+    # quarter of the block's rows each; kind 2 the last candidate column (dx = +R), one candidate per lane (tight plan, n = 4G+1)
+    covered = np.zeros((4 * groups.value, n), np.int32)
+    cost = 0.0
     for r in range(nr.value):
-        s = int(rounds[r])
-        assert s in ((8, 4, 2, 1) if block == 32 or waves == 2 else (16, 8, 4, 2, 1))
+        s, kind = int(rounds[r]) & 0xFF, int(rounds[r]) >> 8
+        assert kind in (0, 1, 2)
         busy = 0
-        for t in tasks[r]:
+        if kind == 0:
+            assert s in ((8, 4, 2, 1) if block == 32 or waves == 2 else (16, 8, 4, 2, 1))
+            cost += s
+        else:
+            assert block <= 16 and n % 4 == 1 and s == 1
+            cost += 0.25
+        quads = {}
+        for lane, t in enumerate(tasks[r]):
             if t == 0xFFFFFFFF:
                 continue
             busy += 1
-            g, dy0 = int(t & 0xFF), int((t >> 8) & 0xFF)
-            assert g < groups.value and dy0 + s <= n
-            covered[g, dy0:dy0 + s] += 1
+            if kind == 0:
+                g, dy0 = int(t & 0xFF), int((t >> 8) & 0xFF)
+                assert g < groups.value and dy0 + s <= n
+                covered[4 * g:4 * g + 4, dy0:dy0 + s] += 1
+            elif kind == 1:
+                g, dyi, part = int(t & 0xFF), int((t >> 8) & 0xFF), int((t >> 16) & 3)
+                assert part == lane % 4 and g < groups.value - 1 and dyi < n
+                quads.setdefault((lane // 4, g, dyi), []).append(part)
+            else:
+                covered[n - 1, int(t & 0xFF)] += 1
+        for (_, g, dyi), parts in quads.items():
+            assert parts == [0, 1, 2, 3]
+            covered[4 * g:4 * g + 4, dyi] += 1
         assert 1 <= busy <= lanes
-        if r < nr.value - 1:
+        if r < nr.value - 1 and kind == 0 and (int(rounds[r + 1]) >> 8) == 0:
             assert busy == lanes or s == 1
-    assert np.all(covered == 1)
-    # a round costs its strip height; the plan should stay close to the ideal n * groups / lanes
-    cost = int(sum(int(rounds[r]) for r in range(nr.value)))
+    assert np.all(covered[:n] == 1)
+    # a round costs its strip height (rim rounds a quarter of a row); the plan should stay close to the ideal n * n / 4 / lanes
     assert cost <= -(-n * groups.value // lanes) + 2
+    if n % 4 == 1 and n >= 9 and block <= 16:
+        assert cost <= n * n / 4.0 / lanes + 1.6
