@@ -372,11 +372,38 @@ __device__ __forceinline__ uint32_t search_strip(const uint32_t *win, int P, con
         const int dxi = 4 * g + c;
         if (dxi > 2 * a.range || (border && (dxi < xlo || dxi > xhi))) colmask |= 0xffffull << (16 * c);
     }
-    const uint16_t *rk = a.rank_of + (size_t)dy0 * a.rank_pitch + 4 * g;
+    // rank rows: uniform base (advanced in scalar registers) + one 32-bit byte offset per lane
+    const char *rk = reinterpret_cast<const char *>(a.rank_of);
+    const uint32_t rk_off = ((uint32_t)dy0 * (uint32_t)a.rank_pitch + 4u * (uint32_t)g) * 2u;
+    const uint32_t rk_step = (uint32_t)a.rank_pitch * 2u;
+    if constexpr (!WIDE) {
+        // away from the image border, in a round without idle lanes or padding columns (every strip round of the tight plan),
+        // no candidate needs masking: four v_perm and the minimum per candidate row, nothing else
+        if (!border && !__ballot(colmask != 0ull)) {
+            constexpr int CH = S < 8 ? S : 8;               // rank rows in flight at a time (registers: the sums are live too)
+#pragma unroll
+            for (int d0 = 0; d0 < S; d0 += CH) {
+                uint2 r4[CH];
+#pragma unroll
+                for (int d = 0; d < CH; ++d) { r4[d] = *reinterpret_cast<const uint2 *>(rk + rk_off); rk += rk_step; }
+#pragma unroll
+                for (int d = 0; d < CH; ++d) {
+                    const uint32_t lo = (uint32_t)acc[d0 + d], hi = (uint32_t)(acc[d0 + d] >> 32);
+                    const uint32_t k0 = __builtin_amdgcn_perm(lo, r4[d].x, 0x05040100u);
+                    const uint32_t k1 = __builtin_amdgcn_perm(lo, r4[d].x, 0x07060302u);
+                    const uint32_t k2 = __builtin_amdgcn_perm(hi, r4[d].y, 0x05040100u);
+                    const uint32_t k3 = __builtin_amdgcn_perm(hi, r4[d].y, 0x07060302u);
+                    best = min(best, min(min(k0, k1), min(k2, k3)));
+                }
+                asm volatile("" ::: "memory");
+            }
+            return best;
+        }
+    }
 #pragma unroll
     for (int d = 0; d < S; ++d) {
-        const uint2 r4 = *reinterpret_cast<const uint2 *>(rk);
-        rk += a.rank_pitch;
+        const uint2 r4 = *reinterpret_cast<const uint2 *>(rk + rk_off);
+        rk += rk_step;
         const bool row_bad = border && (dy0 + d < ylo || dy0 + d > yhi);
         if constexpr (!WIDE) {
             unsigned long long v = acc[d] | colmask;
