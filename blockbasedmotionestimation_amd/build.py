@@ -17,7 +17,7 @@ CLI = os.path.join(PKG, "bbme_cli")
 RCCL_LIB = os.path.join(PKG, "libbbme_rccl.so")
 SEQ = os.path.join(PKG, "bbme_seq")
 SOURCES = ["bbme_host.cpp", "bbme_device.hip"]
-HEADERS = ["bbme_internal.hpp", "bbme_kernels.hpp", "motion_framework.hpp", "rw_flow.hpp", "bbme_main.cpp",
+HEADERS = ["bbme_internal.hpp", "bbme_kernels.hpp", "motion_framework.hpp", "rw_flow.hpp", "bbme_main.cpp", "seq_schedule.hpp",
            "bbme_rccl.cpp", "bbme_seq_main.cpp", os.path.join(ROOT, "include", "bbme.h"), os.path.join(ROOT, "include", "bbme_rccl.h")]
 ARCH = "gfx950"
 

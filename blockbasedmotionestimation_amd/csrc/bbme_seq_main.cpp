@@ -5,7 +5,9 @@
 // Pair p runs on GPU p mod N (one context per GPU, whole pyramid, no exchange: SURVEY.md 8e); after every round of N
 // pairs the compact cell grids are gathered on GPU 0 with one ncclGather (bbme_gather_cells), downloaded in one copy and
 // written as DIR/0000.flo, 0001.flo, ... by the asynchronous writer, which expands them to the dense fields as it
-// writes, while the next round runs.
+// writes.  The round loop is csrc/seq_schedule.hpp (run_sequence): frames are pinned where they were read and uploaded
+// without a host wait (bbme_set_frames_host_async), receive and staging buffers are double-buffered, the download of round
+// k runs on a copy stream beside the estimates of round k + 1, and the host only ever waits for work of the round before.
 // One process drives all N GPUs here (ncclCommInitAll); bbme_gather_cells itself does not care who owns the ranks.
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
@@ -18,10 +20,11 @@
 #include <vector>
 
 #include "bbme_rccl.h"
+#include "seq_schedule.hpp"
 
-#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
-#define NCCL_OK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { fprintf(stderr, "%s: %s\n", #x, ncclGetErrorString(r_)); return 1; } } while (0)
-#define BBME_OKAY(x) do { int s_ = (x); if (s_ != BBME_OK) { fprintf(stderr, "%s: %s\n", #x, bbme_last_error()); return 1; } } while (0)
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+#define NCCL_OK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { fprintf(stderr, "%s: %s\n", #x, ncclGetErrorString(r_)); exit(1); } } while (0)
+#define BBME_OKAY(x) do { int s_ = (x); if (s_ != BBME_OK) { fprintf(stderr, "%s: %s\n", #x, bbme_last_error()); exit(1); } } while (0)
 
 static bool read_pgm(const char *path, std::vector<uint8_t> &px, int &w, int &h)
 {
@@ -44,6 +47,94 @@ static bool read_pgm(const char *path, std::vector<uint8_t> &px, int &w, int &h)
     fclose(f);
     return ok;
 }
+
+namespace {
+
+// run_sequence's backend over HIP streams, RCCL and the asynchronous writer (see seq_schedule.hpp for the contract)
+struct HipBackend {
+    int gpus = 0, n_pairs = 0, w = 0, h = 0, pw = 0, ph = 0, pad_x = 0, pad_y = 0;
+    size_t words = 0;
+    std::vector<std::vector<uint8_t>> *img = nullptr;
+    std::vector<bbme_ctx *> ctx;
+    std::vector<ncclComm_t> comms;
+    std::vector<hipStream_t> stream;               // the contexts' streams
+    hipStream_t copy_stream = nullptr;             // GPU 0: downloads beside the next round's estimates
+    int32_t *d_recv[2] = {nullptr, nullptr};
+    int32_t *host[2] = {nullptr, nullptr};         // pinned
+    hipEvent_t ev_gathered[2] = {nullptr, nullptr}, ev_downloaded[2] = {nullptr, nullptr};
+    bool downloaded_once[2] = {false, false};
+    bbme_flo_writer *writer = nullptr;
+    std::string out_dir;
+    // per-round phase stamps of GPU 0 (timing events): start, frames up + pyramid, estimate, gather on its stream; download on the copy stream
+    std::vector<hipEvent_t> t_start, t_frames, t_estimate, t_gather, t_download;
+    int round = 0;
+
+    hipEvent_t stamp(hipStream_t s)
+    {
+        hipEvent_t e;
+        HIP_OK(hipSetDevice(0));
+        HIP_OK(hipEventCreate(&e));
+        HIP_OK(hipEventRecord(e, s));
+        return e;
+    }
+    void upload(int r, int pair)
+    {
+        if (r == 0) t_start.push_back(stamp(stream[0]));
+        BBME_OKAY(bbme_set_frames_host_async(ctx[r], 0, (*img)[2 * pair].data(), (*img)[2 * pair + 1].data(), w));   // no host wait
+        if (r == 0) t_frames.push_back(stamp(stream[0]));
+    }
+    void estimate(int r)
+    {
+        BBME_OKAY(bbme_estimate(ctx[r]));
+        if (r == 0) t_estimate.push_back(stamp(stream[0]));
+    }
+    void root_wait_downloaded(int b)
+    {
+        HIP_OK(hipSetDevice(0));
+        if (downloaded_once[b]) HIP_OK(hipStreamWaitEvent(stream[0], ev_downloaded[b], 0));
+    }
+    void gather(int b)
+    {
+        NCCL_OK(ncclGroupStart());
+        for (int r = 0; r < gpus; ++r) BBME_OKAY(bbme_gather_cells(ctx[r], comms[r], 0, d_recv[b]));
+        NCCL_OK(ncclGroupEnd());
+    }
+    void record_gathered(int b)
+    {
+        HIP_OK(hipSetDevice(0));
+        HIP_OK(hipEventRecord(ev_gathered[b], stream[0]));
+        t_gather.push_back(stamp(stream[0]));
+    }
+    void host_wait_writer(int k) { if (k >= 0) BBME_OKAY(bbme_flo_writer_wait(writer)); }   // everything submitted so far = rounds <= k
+    void download(int b)
+    {
+        HIP_OK(hipSetDevice(0));
+        HIP_OK(hipStreamWaitEvent(copy_stream, ev_gathered[b], 0));
+        HIP_OK(hipMemcpyAsync(host[b], d_recv[b], words * gpus * sizeof(int32_t), hipMemcpyDeviceToHost, copy_stream));
+    }
+    void record_downloaded(int b)
+    {
+        HIP_OK(hipSetDevice(0));
+        HIP_OK(hipEventRecord(ev_downloaded[b], copy_stream));
+        downloaded_once[b] = true;
+        t_download.push_back(stamp(copy_stream));
+    }
+    void host_wait_downloaded(int b) { HIP_OK(hipEventSynchronize(ev_downloaded[b])); }
+    void submit_files(int k, int b)
+    {
+        for (int r = 0; r < gpus; ++r) {
+            const int p = k * gpus + r;
+            if (p >= n_pairs) continue;
+            char name[32];
+            snprintf(name, sizeof name, "/%04d.flo", p);
+            const std::string path = out_dir + name;
+            BBME_OKAY(bbme_flo_writer_submit_cells(writer, path.c_str(), w, h, reinterpret_cast<const int16_t *>(host[b] + (size_t)r * words),
+                                                   ph / 2, pw / 2, pad_x, pad_y));
+        }
+    }
+};
+
+}  // namespace
 
 int main(int argc, char **argv)
 {
@@ -77,68 +168,62 @@ int main(int argc, char **argv)
         if (i && (wi != w || hi != h)) { fprintf(stderr, "%s: all frames must have one size\n", files[i]); return 1; }
         w = wi; h = hi;
     }
+    // pinned where they are: the uploads are then truly asynchronous (no staging copy, no host wait)
+    for (auto &v : img) HIP_OK(hipHostRegister(v.data(), v.size(), hipHostRegisterPortable));
     bbme_params params{};
     params.num_levels = levels;
     for (int l = 0; l < levels; ++l) { params.block_size[l] = block; params.search_size[l] = search; }
 
+    HipBackend be;
+    be.gpus = gpus; be.n_pairs = n_pairs; be.w = w; be.h = h; be.img = &img; be.out_dir = out_dir;
     std::vector<int> devs(gpus);
     for (int r = 0; r < gpus; ++r) devs[r] = r;
-    std::vector<ncclComm_t> comms(gpus);
-    NCCL_OK(ncclCommInitAll(comms.data(), gpus, devs.data()));
-    std::vector<bbme_ctx *> ctx(gpus, nullptr);
+    be.comms.resize(gpus);
+    NCCL_OK(ncclCommInitAll(be.comms.data(), gpus, devs.data()));
+    be.ctx.assign(gpus, nullptr);
+    be.stream.assign(gpus, nullptr);
     for (int r = 0; r < gpus; ++r) {
-        BBME_OKAY(bbme_create(&params, w, h, r, &ctx[r]));
+        BBME_OKAY(bbme_create(&params, w, h, r, &be.ctx[r]));
+        void *s = nullptr;
+        BBME_OKAY(bbme_get_stream(be.ctx[r], &s));
+        be.stream[r] = static_cast<hipStream_t>(s);
     }
-    int pw = 0, ph = 0, pad_x = 0, pad_y = 0;
-    BBME_OKAY(bbme_get_geometry(ctx[0], &pw, &ph, &pad_x, &pad_y));
-    const size_t words = (size_t)(pw / 2) * (ph / 2);
-    int32_t *d_recv = nullptr;
+    BBME_OKAY(bbme_get_geometry(be.ctx[0], &be.pw, &be.ph, &be.pad_x, &be.pad_y));
+    be.words = (size_t)(be.pw / 2) * (be.ph / 2);
     HIP_OK(hipSetDevice(0));
-    HIP_OK(hipMalloc(&d_recv, words * gpus * sizeof(int32_t)));
-    void *stream0 = nullptr;
-    BBME_OKAY(bbme_get_stream(ctx[0], &stream0));
-    // pinned staging for the writer: the gathered cell grids of a round (1/16 of the dense fields), double-buffered over
-    // rounds; the writer expands them while it writes (bbme_flo_writer_submit_cells)
-    int32_t *host[2] = {nullptr, nullptr};
-    for (auto &p : host) HIP_OK(hipHostMalloc(&p, words * gpus * sizeof(int32_t)));
-    bbme_flo_writer *writer = nullptr;
-    BBME_OKAY(bbme_flo_writer_create(&writer));
+    HIP_OK(hipStreamCreateWithFlags(&be.copy_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+        HIP_OK(hipMalloc(&be.d_recv[b], be.words * gpus * sizeof(int32_t)));
+        // pinned staging for the writer: the gathered cell grids of a round (1/16 of the dense fields); the writer expands them
+        // while it writes (bbme_flo_writer_submit_cells)
+        HIP_OK(hipHostMalloc(&be.host[b], be.words * gpus * sizeof(int32_t)));
+        HIP_OK(hipEventCreateWithFlags(&be.ev_gathered[b], hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&be.ev_downloaded[b], hipEventDisableTiming));
+    }
+    BBME_OKAY(bbme_flo_writer_create(&be.writer));
 
     const auto t0 = std::chrono::steady_clock::now();
-    const int rounds = (n_pairs + gpus - 1) / gpus;
-    for (int k = 0; k < rounds; ++k) {
-        for (int r = 0; r < gpus; ++r) {
-            const int p = k * gpus + r;
-            if (p >= n_pairs) continue;                       // this rank idles in the last round but still joins the gather
-            BBME_OKAY(bbme_set_frames_host(ctx[r], img[2 * p].data(), img[2 * p + 1].data(), w));
-            BBME_OKAY(bbme_estimate(ctx[r]));
-        }
-        NCCL_OK(ncclGroupStart());
-        for (int r = 0; r < gpus; ++r) BBME_OKAY(bbme_gather_cells(ctx[r], comms[r], 0, d_recv));
-        NCCL_OK(ncclGroupEnd());
-        if (k >= 2) BBME_OKAY(bbme_flo_writer_wait(writer));  // the staging buffers of round k - 2 are free again
-        int32_t *dst = host[k & 1];
-        HIP_OK(hipMemcpyAsync(dst, d_recv, words * gpus * sizeof(int32_t), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream0)));
-        HIP_OK(hipStreamSynchronize(static_cast<hipStream_t>(stream0)));
-        for (int r = 0; r < gpus; ++r) {
-            const int p = k * gpus + r;
-            if (p >= n_pairs) continue;
-            char name[32];
-            snprintf(name, sizeof name, "/%04d.flo", p);
-            const std::string path = std::string(out_dir) + name;
-            BBME_OKAY(bbme_flo_writer_submit_cells(writer, path.c_str(), w, h, reinterpret_cast<const int16_t *>(dst + (size_t)r * words),
-                                                   ph / 2, pw / 2, pad_x, pad_y));
-        }
-    }
-    for (int r = 0; r < gpus; ++r) BBME_OKAY(bbme_synchronize(ctx[r]));       // also refuses a field that did not converge
-    BBME_OKAY(bbme_flo_writer_wait(writer));
+    bbme::run_sequence(be, gpus, n_pairs);
+    for (int r = 0; r < gpus; ++r) BBME_OKAY(bbme_synchronize(be.ctx[r]));       // also refuses a field that did not converge
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     printf("%d pairs of %dx%d on %d GPU(s): %.3f s (%.2f ms per pair, files included)\n", n_pairs, w, h, gpus, secs,
            secs / n_pairs * 1e3);
+    // per-round phases on GPU 0 (device time between stamps; the download runs on the copy stream beside the next round)
+    const size_t rounds = be.t_gather.size();
+    for (size_t k = 0; k < rounds && k < be.t_start.size(); ++k) {
+        float up = 0, est = 0, ga = 0, dl = 0, cycle = 0;
+        HIP_OK(hipEventElapsedTime(&up, be.t_start[k], be.t_frames[k]));
+        HIP_OK(hipEventElapsedTime(&est, be.t_frames[k], be.t_estimate[k]));
+        HIP_OK(hipEventElapsedTime(&ga, be.t_estimate[k], be.t_gather[k]));
+        HIP_OK(hipEventElapsedTime(&dl, be.t_gather[k], be.t_download[k]));
+        if (k + 1 < be.t_start.size()) HIP_OK(hipEventElapsedTime(&cycle, be.t_start[k], be.t_start[k + 1]));
+        printf("round %zu: upload+pyramid %.3f ms, estimate %.3f ms, gather %.3f ms, download (copy stream, from the gather's end) %.3f ms, "
+               "next round starts after %.3f ms\n", k, up, est, ga, dl, cycle);
+    }
 
-    bbme_flo_writer_destroy(writer);
-    for (auto p : host) (void)hipHostFree(p);
-    (void)hipFree(d_recv);
-    for (int r = 0; r < gpus; ++r) { bbme_destroy(ctx[r]); ncclCommDestroy(comms[r]); }
+    bbme_flo_writer_destroy(be.writer);
+    for (auto &v : img) (void)hipHostUnregister(v.data());
+    for (int b = 0; b < 2; ++b) { (void)hipHostFree(be.host[b]); (void)hipFree(be.d_recv[b]); }
+    for (int r = 0; r < gpus; ++r) { bbme_destroy(be.ctx[r]); ncclCommDestroy(be.comms[r]); }
     return 0;
 }

@@ -1,10 +1,18 @@
-"""Frame pairs of a sequence sharded one pair per GPU.
+"""Frame pairs of a sequence over GPUs and within one GPU.
 
 Pairs are independent in the reference (an MF object holds all state of one pair,
-motion_framework.h:37-46; nothing is carried from pair to pair), so pair p goes to rank
-p % world_size and runs the whole pyramid there with no exchange.  The only collective is the
-gather of the finished dense .flo fields on rank 0 at the end (torch.distributed: backend
-"nccl" is RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+motion_framework.h:37-46; nothing is carried from pair to pair), so they shard with no exchange:
+
+* across GPUs -- pair p goes to rank p % world_size (one process per GPU) and runs the whole pyramid there; the only
+  collective is ONE gather per step of the results on rank 0.  `CellGather` / `mf_cell_gather` is that step as
+  `bench.py --gpus N` runs it: the results travel as compact int16 cell grids (1/16 of the dense field), staging buffers are
+  double-buffered, and rank 0 expands the gathered grids to the dense .flo fields on a second stream beside the next
+  estimate.  (`csrc/seq_schedule.hpp` + `bbme_seq` is the same pipeline in C++ over RCCL, without torch.)
+* within a GPU -- `estimate_pairs_pipelined`: the pairs that share a GPU go into BATCHED contexts (`MFBatch`,
+  bbme_create_batch: every kernel works on all pairs of a context at once), a few contexts side by side on their own streams.
+* `estimate_sequence` is the convenience form on top of any `compute` callable and any torch.distributed backend ("nccl" is
+  RCCL over xGMI on ROCm; "gloo" in the CPU tests): it gathers the finished dense fields round by round and optionally writes
+  the .flo files.  It is not the timed path.
 """
 import os
 
@@ -132,46 +140,53 @@ def shard_pairs(n_pairs, rank, world_size):
     return list(range(rank, n_pairs, world_size))
 
 
-def estimate_pairs_pipelined(pairs, search_size, block_size, device=None, in_flight=4):
+def estimate_pairs_pipelined(pairs, search_size, block_size, device=None, in_flight=4, batch=2):
     """All pairs of `pairs` (a list of (frame1, frame2), equal sizes) on ONE GPU, `in_flight` of them at a time.
 
-    One context per slot, created once (level state, launch graph) and re-used round-robin; every
-    context has its own stream, so while one pair's regulariser walks its dependency chains the
-    chip works on the others.  Returns the unpadded (H, W, 2) float32 fields in input order.
-    The result of a pair does not depend on what else is in flight (tests/test_gpu_parity.py).
-    HIP maps streams onto 4 hardware queues by default; with more pairs than that in flight export
-    GPU_MAX_HW_QUEUES (e.g. 16) before the process starts the HIP runtime (4 pairs: 21 -> 30 Mblocks/s on cfg3).
+    The pairs go, `batch` at a time, into batched contexts (MFBatch: one launch sequence for all pairs of the context, the
+    pair is a grid dimension), in_flight // batch contexts created once (level state, launch graph) and re-used round-robin,
+    each on its own stream: while one context's regulariser walks its dependency chains the chip searches for another.
+    Why batches: the device dispatches the dependent kernels of many streams no faster than one per ~4 us chip-wide, so one
+    context per pair is dispatch-bound at 69 launches per pair (8 pairs at 4K: 34 Mblocks/s with 8 contexts x 1 pair,
+    45 with 4 x 2).  Returns the unpadded (H, W, 2) float32 fields in input order; a pair's result does not depend on
+    what shares its context or the GPU (tests/test_gpu_parity.py).  More than 4 streams: export GPU_MAX_HW_QUEUES (e.g. 16)
+    before the process starts the HIP runtime.
     """
-    from .motion_framework import MF
+    from .motion_framework import MFBatch
     if not pairs:
         return []
     if device is None:
         device = local_device()
+    per = max(1, min(batch, in_flight, len(pairs)))
+    n_slots = max(1, in_flight // per)
+    groups = [list(range(i, min(i + per, len(pairs)))) for i in range(0, len(pairs), per)]
     slots = []
     out = [None] * len(pairs)
-    pending = []                                           # (slot, pair index), oldest first
+    pending = []                                           # (slot, pair indices), oldest first
 
     def collect():
-        slot, idx = pending.pop(0)
+        slot, idxs = pending.pop(0)
         mf = slots[slot]
-        h, w = pairs[idx][0].shape
-        flow = mf.get_flow()                               # waits for this context's stream only
-        out[idx] = np.ascontiguousarray(flow[mf.padding_y:mf.padding_y + h, mf.padding_x:mf.padding_x + w])
+        for p, idx in enumerate(idxs):
+            h, w = pairs[idx][0].shape
+            flow = mf.get_pair_flow(p)                     # waits for this context's stream only
+            out[idx] = np.ascontiguousarray(flow[mf.padding_y:mf.padding_y + h, mf.padding_x:mf.padding_x + w])
 
     try:
-        for idx, (f1, f2) in enumerate(pairs):
-            if len(slots) < max(1, in_flight):
-                slots.append(MF(f1, f2, search_size, block_size, len(block_size), device=device))
+        for idxs in groups:
+            frames = [pairs[i] for i in idxs] + [pairs[idxs[-1]]] * (per - len(idxs))     # a short last group: padded, not read
+            if len(slots) < n_slots:
+                slots.append(MFBatch(frames, search_size, block_size, len(block_size), device=device))
                 slot = len(slots) - 1
-                if in_flight > 1:
+                if n_slots * per > 1:
                     slots[slot].set_speculation(False)      # the other pairs in flight fill the chip already
-                    slots[slot].set_relaxation(False)
             else:
                 slot = pending[0][0]
                 collect()
-                slots[slot].set_frames(f1, f2)
+                for p, (f1, f2) in enumerate(frames):
+                    slots[slot].set_pair(p, f1, f2)
             slots[slot].estimate_async()
-            pending.append((slot, idx))
+            pending.append((slot, idxs))
         while pending:
             collect()
     finally:

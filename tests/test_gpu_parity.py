@@ -529,8 +529,8 @@ def test_pipelined_sequence_matches_oracle_per_pair(bbme, oracle):
         py, px = omf.padding_y, omf.padding_x
         expect.append(full[py:py + 200, px:px + 328])
         omf.close()
-    for k in (1, 3, 16):
-        got = estimate_pairs_pipelined(pairs, search, block, in_flight=k)
+    for k, per in ((1, 1), (3, 1), (4, 2), (6, 3), (16, 2), (16, 8)):      # pairs in flight, pairs per batched context
+        got = estimate_pairs_pipelined(pairs, search, block, in_flight=k, batch=per)
         assert len(got) == len(pairs)
         for g, e in zip(got, expect):
             assert g.shape == (200, 328, 2) and np.array_equal(g, e)
@@ -689,14 +689,16 @@ def test_raster_search_ties_and_outside_predictions(bbme, oracle):
 
 
 def test_cpp_sequence_driver_over_rccl(bbme, oracle, tmp_path):
-    """bbme_seq: the multi-GPU sequence without torch -- contexts per GPU, ncclGather of the cell grids through
-    libbbme_rccl.so (bbme_gather_cells), expansion on the root, asynchronous .flo writer -- here with the one GPU of this
-    box (an RCCL communicator of size one, three pairs = three rounds): every file equals the oracle's field."""
+    """bbme_seq: the multi-GPU sequence without torch -- contexts per GPU, asynchronous uploads from pinned frames,
+    ncclGather of the cell grids through libbbme_rccl.so (bbme_gather_cells) into double-buffered receive buffers, download on
+    a copy stream beside the next round, asynchronous .flo writer (csrc/seq_schedule.hpp) -- here with the one GPU of this box
+    (an RCCL communicator of size one, five pairs = five rounds, so that both buffers are re-used twice): every file equals
+    the oracle's field, and the driver prints its per-round phase times."""
     import subprocess
     from blockbasedmotionestimation_amd import build as _build
-    search, block = 40, 8
+    search, block, n = 40, 8, 5
     files, expect = [], []
-    for p in range(3):
+    for p in range(n):
         f1, f2, _ = bbme.synth_pair(328, 200, 8800 + p, max_motion=10)
         for tag, img in (("a", f1), ("b", f2)):
             path = str(tmp_path / ("%d%s.pgm" % (p, tag)))
@@ -709,8 +711,9 @@ def test_cpp_sequence_driver_over_rccl(bbme, oracle, tmp_path):
     r = subprocess.run([_build.SEQ, "--gpus", "1", "--levels", "3", "--block", str(block), "--search", str(search),
                         "--out", str(tmp_path)] + files, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    assert "3 pairs of 328x200 on 1 GPU(s)" in r.stdout
-    for p in range(3):
+    assert "%d pairs of 328x200 on 1 GPU(s)" % n in r.stdout
+    assert r.stdout.count("upload+pyramid") == n and "round %d:" % (n - 1) in r.stdout      # per-phase times of every round
+    for p in range(n):
         got = bbme.Flow().ReadFlowFile(str(tmp_path / ("%04d.flo" % p)))
         assert np.array_equal(got, expect[p]), "pair %d" % p
 
