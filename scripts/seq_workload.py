@@ -18,7 +18,8 @@ ap.add_argument("--workload", default="cfg3")
 ap.add_argument("--pairs", type=int, default=8)
 ap.add_argument("--steps", type=int, default=4)
 ap.add_argument("--speculate", type=int, default=0)
-ap.add_argument("--relax", type=int, default=0)
+ap.add_argument("--relax", type=int, default=1)
+ap.add_argument("--batch", type=int, default=1, help="pairs per batched context (bbme_create_batch)")
 a = ap.parse_args()
 
 import blockbasedmotionestimation_amd as bbme                    # noqa: E402
@@ -26,9 +27,9 @@ from bench import WORKLOADS                                      # noqa: E402
 
 w, h, search, block, levels, _ = WORKLOADS[a.workload]
 ctxs = []
-for k in range(a.pairs):
-    f1, f2, _ = bbme.synth_pair(w, h, 1030 + k, max_motion=24)
-    mf = bbme.MF(f1, f2, [search] * levels, [block] * levels, levels)
+frames = [bbme.synth_pair(w, h, 1030 + k, max_motion=24)[:2] for k in range(a.pairs)]
+for i in range(0, a.pairs, a.batch):
+    mf = bbme.MFBatch(frames[i:i + a.batch], [search] * levels, [block] * levels, levels)
     mf.set_speculation(bool(a.speculate))
     mf.set_relaxation(bool(a.relax))
     ctxs.append(mf)
@@ -44,7 +45,7 @@ for c in ctxs:
     c.synchronize()
 dt = time.perf_counter() - t0
 blocks0 = (ctxs[0].padded_width // block) * (ctxs[0].padded_height // block)
-print("seq workload: %d pairs x %d steps, %.3f ms per pair, %.2f Mblocks/s" %
-      (a.pairs, a.steps, dt / (a.pairs * a.steps) * 1e3, blocks0 * a.pairs * a.steps / dt / 1e6))
+print("seq workload: %d pairs (%d contexts x %d) x %d steps, %.3f ms per pair, %.2f Mblocks/s" %
+      (a.pairs, len(ctxs), a.batch, a.steps, dt / (a.pairs * a.steps) * 1e3, blocks0 * a.pairs * a.steps / dt / 1e6))
 for c in ctxs:
     c.close()

@@ -1,0 +1,12 @@
+#!/usr/bin/env python3
+"""Development aid: the kernel sequence of one graph-replayed pyramid from a rocprofv3 kernel trace (start, duration, name, grid)."""
+import csv, glob, os, sys
+f = max(glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True), key=os.path.getmtime)
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
+idx = [i for i, r in enumerate(rows) if 'k_expand' in r['Kernel_Name']]
+a, b = idx[len(idx) // 2] + 1, idx[len(idx) // 2 + 1] + 1
+t0 = int(rows[a]['Start_Timestamp'])
+for r in rows[a:b]:
+    s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+    n = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('bbme::', '')
+    print("%9.1f %7.1f  %-40s grid=%s" % ((s - t0) / 1e3, (e - s) / 1e3, n, r.get('Grid_Size_X', r.get('Grid_Size', '?'))))
