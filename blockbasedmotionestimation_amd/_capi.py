@@ -113,7 +113,6 @@ SIGNATURES = {
     "bbme_set_regularizer_mode": (C.c_int, [_ctx, C.c_int]),
     "bbme_set_speculation": (C.c_int, [_ctx, C.c_int]),
     "bbme_set_relaxation": (C.c_int, [_ctx, C.c_int]),
-    "bbme_set_lookahead": (C.c_int, [_ctx, C.c_int]),
     "bbme_wait_for_stream": (C.c_int, [_ctx, C.c_void_p]),
     "bbme_calibrate_read": (C.c_int, [C.c_int, C.c_uint, C.c_int]),
     "bbme_selftest_isa": (C.c_int, [C.c_int, _P(C.c_int)]),

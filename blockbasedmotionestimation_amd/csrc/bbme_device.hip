@@ -31,19 +31,12 @@ struct Level {
     // small[0] -> small[1] -> small[0], which then stays untouched until the level's next search: the speculative search
     // of the next finer level predicts from it).  big[]: grids at b < B (capacity (H/2)*(W/2)), ping-pong.
     mv_t *small[2] = {nullptr, nullptr};
-    mv_t *big[3] = {nullptr, nullptr, nullptr};   // three: with the look-ahead, pass 1 of a sweep writes its grid while the solver of the
-                                                  // sweep before still reads the grid before that one as its old values
+    mv_t *big[2] = {nullptr, nullptr};
     mv_t *cur_grid = nullptr;                     // the grid that holds the current field
     int cur_block = 0;                            // its block size (0 = nothing yet)
     mv_t *pred = nullptr;                         // per block: the coarse MV a speculative search started from
     uint32_t *fix_list = nullptr, *fix_count = nullptr;   // blocks to search again after a speculative search
-    // where two sweeps per block size leave the 2x2 cells: the sweeps below the level's own block size rotate through big[0..2]
-    mv_t *final_grid() const
-    {
-        int n = 0;
-        for (int b = block >> 1; b > 1; b >>= 1) n += 2;
-        return n == 0 ? small[0] : big[(n - 1) % 3];
-    }
+    mv_t *final_grid() const { return block == 2 ? small[0] : big[1]; }   // where two sweeps per block size leave the 2x2 cells
     uint32_t *spiral = nullptr;                   // rank -> packed (dx, dy)
     int ncand = 0;
     int pitch_dw = 0;
@@ -81,11 +74,7 @@ struct bbme_ctx {
     std::vector<Level> lv;
     float *flow = nullptr;                        // dense padded H0 x W0 float2
     uint32_t *list[2] = {nullptr, nullptr};
-    uint8_t *flags[4] = {nullptr, nullptr, nullptr, nullptr};   // dirty flags of the regulariser, one byte per block, all zero between sweeps:
-                                                  // two sets of two (sweeps alternate: a sweep's pass 1 may run beside the solver of the one before)
-    unsigned sweep_seq = 0;                       // sweeps enqueued so far: its parity picks the flag set and the counter set
-    int last_counter_set = 0;                     // the counter set (0 / 1) of the sweep enqueued last (diagnostics)
-    bool lookahead = true;                        // pass 1 of the first sweep at half the block size in the launch of the solver before it; BBME_LOOKAHEAD
+    uint8_t *flags[2] = {nullptr, nullptr};       // dirty flags of the regulariser, one byte per block, all zero between sweeps
     size_t flag_bytes = 0;
     int relax_steps = -1;                         // k_reg_iter launches per sweep; -1 = by grid size (BBME_RELAX_STEPS overrides)
     bool split_forced = false;                    // threshold given in the environment: split whatever the plans' lengths (tests)
@@ -144,16 +133,17 @@ void drop_graph(bbme_ctx *c)
 // that path the solver's ownership words and counters are stale too: cleared, so that the context stays usable.
 int check_converged(bbme_ctx *c)
 {
-    std::vector<uint32_t> flags((size_t)c->batch * 4, 0u);    // word 5 of every 16: the sticky flag of both counter sets of every pair
-    HIP_TRY(hipMemcpy2DAsync(flags.data(), sizeof(uint32_t), c->counters + 5, 16 * sizeof(uint32_t), sizeof(uint32_t),
-                             (size_t)c->batch * 4, hipMemcpyDeviceToHost, c->stream));
+    std::vector<uint32_t> flags((size_t)c->batch, 0u);    // counters[5] of every pair (64 words apart)
+    HIP_TRY(hipMemcpy2DAsync(flags.data(), sizeof(uint32_t), c->counters + 5, 64 * sizeof(uint32_t), sizeof(uint32_t),
+                             (size_t)c->batch, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     bool flag = false;
     for (uint32_t f : flags) flag = flag || f != 0;
     if (!flag) return BBME_OK;
     HIP_TRY(hipMemsetAsync(c->own, 0, (size_t)c->own_stride * 4 * c->batch, c->stream));
     HIP_TRY(hipMemsetAsync(c->counters, 0, (size_t)256 * c->batch, c->stream));
-    for (uint8_t *f : c->flags) HIP_TRY(hipMemsetAsync(f, 0, c->flag_bytes * c->batch, c->stream));
+    HIP_TRY(hipMemsetAsync(c->flags[0], 0, c->flag_bytes * c->batch, c->stream));
+    HIP_TRY(hipMemsetAsync(c->flags[1], 0, c->flag_bytes * c->batch, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return bbme::fail(BBME_ERR_STATE, "a regulariser sweep hit its round cap without converging: the motion field is not "
                                       "the reference's and has been discarded");
@@ -182,8 +172,8 @@ int set_prediction_source(bbme_ctx *c, int level, int mode, Args &a)
     Level &C = c->lv[level + 1];
     a.coarse_block = C.block;
     if (mode == kSearchSpeculative) {
-        // (called right after the two sweeps at the level's own block size are enqueued; the host-side cursor may already
-        // point at the next sweep, whose pass 1 the look-ahead has started)
+        if (C.cur_block != C.block || C.cur_grid != C.small[0])
+            return bbme::fail(BBME_ERR_STATE, "level %d is not at the end of the sweeps at its own block size", level + 1);
         a.coarse = C.small[0];
         a.coarse_cell_shift = 0;
         while ((1 << a.coarse_cell_shift) < C.block) ++a.coarse_cell_shift;
@@ -286,82 +276,47 @@ int launch_search(bbme_ctx *c, int level, int mode = kSearchPlain, hipStream_t s
     return rc;
 }
 
-// One regularize_MVs() sweep = pass 1 (every block with new := old), optionally relaxation launches (large grids of small blocks),
-// then the asynchronous solver.  SweepJob holds what the three launch steps share.
-struct SweepJob {
-    RegArgs a{};
-    int b = 0, steps = 0;
-    uint8_t *flags[2] = {nullptr, nullptr};      // this sweep's flag set: pass 1 marks [0]; relaxation step i consumes [i & 1] and marks the other
-};
-
 template <int BS>
-void launch_pass1_t(RegArgs a, bool jacobi, long long lanes_max, unsigned P, hipStream_t s)
+void launch_sweep_t(RegArgs a, uint8_t *const flags[2], int relax_steps, int max_solve_wgs, int solve_waves, bool jacobi,
+                    long long lanes_max, long long fine_max, unsigned P, hipStream_t s)
 {
     constexpr int LPB = RegCfg<BS>::LPB;
     const long long blocks = (long long)a.rows * a.cols;
     const int grid1 = (int)((blocks * LPB + 255) / 256);
-    // grids up to ~130 000 blocks: the chain form of pass 1 (a third of the instructions per wave; 16 lanes per block fill the
-    // chip from ~32 000 blocks on, and it still wins up to four times that: 1.815 -> 1.78 ms per cfg3 pair; slower from 500 000)
-    if (BS <= 16 && blocks <= lanes_max)                   // (b >= 32: a lane would walk 32+ rows -- 13 against 6 us at b = 32)
-        hipLaunchKernelGGL(k_reg_pass1_lanes<BS>, dim3((unsigned)((blocks * 16 + 255) / 256), P), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL(k_reg_pass1<BS>, dim3(grid1, P), dim3(256), 0, s, a);
-}
-
-template <int BS>
-void launch_relax_t(RegArgs a, unsigned P, hipStream_t s)
-{
-    constexpr int T = RegIter<BS>::T;
-    const unsigned tiles = (unsigned)(((a.cols + T - 1) / T) * ((a.rows + T - 1) / T));
-    hipLaunchKernelGGL(k_reg_iter<BS>, dim3(tiles, P), dim3(256), 0, s, a);
-}
-
-template <int BS>
-void launch_solve_t(RegArgs a, int max_solve_wgs, int solve_waves, long long fine_max, unsigned P, hipStream_t s)
-{
-    const long long blocks = (long long)a.rows * a.cols;
     // a multiple of 8 workgroups: one share per XCD (k_reg_solve's bands)
     const int grid2 = (int)((std::min<long long>(max_solve_wgs, (blocks + 63) / 64) + 7) / 8 * 8);
+    // pass 1 marks flags[0]; relaxation step i consumes flags[i & 1] and marks the other; the solver
+    // consumes what the last step marked.  Every flag is zero again afterwards.
+    // grids up to ~130 000 blocks: the chain form of pass 1 (a third of the instructions per wave; 16 lanes per block fill the
+    // chip from ~32 000 blocks on, and it still wins up to four times that: 1.815 -> 1.78 ms per cfg3 pair; slower from 500 000)
+    auto pass1 = [&]() {
+        if (BS <= 16 && blocks <= lanes_max)               // (b >= 32: a lane would walk 32+ rows -- 13 against 6 us at b = 32)
+            hipLaunchKernelGGL(k_reg_pass1_lanes<BS>, dim3((unsigned)((blocks * 16 + 255) / 256), P), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL(k_reg_pass1<BS>, dim3(grid1, P), dim3(256), 0, s, a);
+    };
+    if (jacobi) {
+        // opt-in, NOT the reference's field: every block against the field as the previous sweep left it, and no more
+        a.flag_cur = nullptr; a.flag_next = nullptr;
+        pass1();
+        return;
+    }
+    a.flag_cur = nullptr; a.flag_next = flags[0];
+    pass1();
+    int cur = 0;
+    for (int i = 0; i < relax_steps; ++i, cur ^= 1) {
+        a.flag_cur = flags[cur]; a.flag_next = flags[cur ^ 1];
+        constexpr int T = RegIter<BS>::T;
+        const unsigned tiles = (unsigned)(((a.cols + T - 1) / T) * ((a.rows + T - 1) / T));
+        hipLaunchKernelGGL(k_reg_iter<BS>, dim3(tiles, P), dim3(256), 0, s, a);
+    }
+    a.flag_cur = flags[cur]; a.flag_next = nullptr;
     // small grids: scan segments of 4 flags, so that the stale blocks of a row are dealt to four times as many waves
     if (blocks <= fine_max) hipLaunchKernelGGL((k_reg_solve<BS, 4>), dim3(grid2, P), dim3(64 * solve_waves), 0, s, a);
     else hipLaunchKernelGGL((k_reg_solve<BS, 16>), dim3(grid2, P), dim3(64 * solve_waves), 0, s, a);
 }
 
-// the solver of a sweep and pass 1 of the next one (at half the block size) in one launch (k_reg_solve_ahead)
-template <int BS>
-void launch_solve_ahead_t(RegArgs a, RegArgs n, int max_solve_wgs, long long fine_max, long long lanes_max, unsigned P, hipStream_t s)
-{
-    if constexpr (BS >= 4 && BS <= 32) {
-        constexpr int NB = BS / 2;
-        const long long blocks = (long long)a.rows * a.cols, nblocks = (long long)n.rows * n.cols;
-        const unsigned grid2 = (unsigned)((std::min<long long>(max_solve_wgs, (blocks + 63) / 64) + 7) / 8 * 8);
-        const bool lanes = NB <= 16 && nblocks <= lanes_max;
-        const unsigned gridp = (unsigned)((nblocks * (lanes ? 16 : RegCfg<NB>::LPB) + 255) / 256);
-        const dim3 grid(grid2 + gridp, P);
-        if (blocks <= fine_max) {
-            if (lanes) hipLaunchKernelGGL((k_reg_solve_ahead<BS, 4, true>), grid, dim3(256), 0, s, a, n, grid2);
-            else hipLaunchKernelGGL((k_reg_solve_ahead<BS, 4, false>), grid, dim3(256), 0, s, a, n, grid2);
-        } else {
-            if (lanes) hipLaunchKernelGGL((k_reg_solve_ahead<BS, 16, true>), grid, dim3(256), 0, s, a, n, grid2);
-            else hipLaunchKernelGGL((k_reg_solve_ahead<BS, 16, false>), grid, dim3(256), 0, s, a, n, grid2);
-        }
-    }
-}
-
-#define BBME_BY_BLOCK(b, CALL)                                                                   \
-    switch (b) {                                                                                 \
-    case 2:  { constexpr int BS = 2; CALL; } break;                                              \
-    case 4:  { constexpr int BS = 4; CALL; } break;                                              \
-    case 8:  { constexpr int BS = 8; CALL; } break;                                              \
-    case 16: { constexpr int BS = 16; CALL; } break;                                             \
-    case 32: { constexpr int BS = 32; CALL; } break;                                             \
-    case 64: { constexpr int BS = 64; CALL; } break;                                             \
-    default: return bbme::fail(BBME_ERR_UNSUPPORTED, "block size %d", b);                        \
-    }
-
-// Everything about the next sweep of `level` at block size b, multiplier mult, from the level's current grid; advances the
-// host-side bookkeeping (Level::cur_grid / cur_block) as if the sweep had run, so that the sweep after it can be prepared too.
-int prepare_sweep(bbme_ctx *c, int level, int b, int mult, SweepJob &job)
+int launch_sweep(bbme_ctx *c, int level, int b, int mult)
 {
     Level &L = c->lv[level];
     if (mult < 1) return bbme::fail(BBME_ERR_INVALID, "lambda multiplier %d", mult);
@@ -377,11 +332,9 @@ int prepare_sweep(bbme_ctx *c, int level, int b, int mult, SweepJob &job)
     a.rows = L.height / b; a.cols = L.width / b;
     a.old_grid = L.cur_grid;
     a.old_cols = a.cols >> a.old_shift;
-    // sweeps at the level's own block size ping-pong in small[]; the others rotate through big[0..2] (see Level)
-    if (b == L.block) a.est = (L.cur_grid == L.small[0]) ? L.small[1] : L.small[0];
-    else if (L.cur_grid == L.big[0]) a.est = L.big[1];
-    else if (L.cur_grid == L.big[1]) a.est = L.big[2];
-    else a.est = L.big[0];
+    // sweeps at the level's own block size ping-pong in small[], the others in big[] (see Level)
+    mv_t *const *pool = (b == L.block) ? L.small : L.big;
+    a.est = (L.cur_grid == pool[0]) ? pool[1] : pool[0];
     // lambda = (float)(B/2), doubled at every halving (motion_framework.cpp:73,95,151); times
     // (float)lambda_multiplier as at :607
     float lambda = (float)(L.block / 2);
@@ -400,12 +353,7 @@ int prepare_sweep(bbme_ctx *c, int level, int b, int mult, SweepJob &job)
     // along the raster dependency chain (< 2 * rows + cols blocks): the cap is an exit every wave reaches even if
     // that reasoning were wrong; hitting it raises counters[5] and the result is refused (BBME_ERR_STATE)
     a.round_cap = c->round_cap > 0 ? (uint32_t)c->round_cap : 64u * (uint32_t)(2 * a.rows + a.cols + 16);
-    // sweeps alternate between two flag sets and two counter sets: pass 1 of a sweep (which also resets the solver's counters)
-    // may run beside the solver of the sweep before it (look-ahead)
-    const unsigned parity = c->sweep_seq++ & 1u;
-    a.counters = c->counters + 16 * parity;
-    c->last_counter_set = (int)parity;
-    job.flags[0] = c->flags[2 * parity]; job.flags[1] = c->flags[2 * parity + 1];
+    a.counters = c->counters;
     // relaxation launches (k_reg_iter, 8 local rounds per tile): one more launch (>= 5 us), which only the sweeps with
     // heavy first generations repay -- measured on cfg3 / cfg4 / cfg2: large grids of small blocks, one launch per sweep
     const long long nblk = (long long)a.rows * a.cols;
@@ -421,96 +369,18 @@ int prepare_sweep(bbme_ctx *c, int level, int b, int mult, SweepJob &job)
         (void)parsed;
         steps = (c->relax && nblk >= min_blocks && b <= max_b) ? (mult == 1 ? s1 : s2) : 0;
     }
-    job.a = a; job.b = b; job.steps = c->jacobi ? 0 : steps;
+    switch (b) {
+    case 2:  launch_sweep_t<2>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, (unsigned)c->batch, c->stream); break;
+    case 4:  launch_sweep_t<4>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, (unsigned)c->batch, c->stream); break;
+    case 8:  launch_sweep_t<8>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, (unsigned)c->batch, c->stream); break;
+    case 16: launch_sweep_t<16>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, (unsigned)c->batch, c->stream); break;
+    case 32: launch_sweep_t<32>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, (unsigned)c->batch, c->stream); break;
+    case 64: launch_sweep_t<64>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, (unsigned)c->batch, c->stream); break;
+    default: return bbme::fail(BBME_ERR_UNSUPPORTED, "block size %d", b);
+    }
+    HIP_TRY(hipGetLastError());
     L.cur_grid = a.est;
     L.cur_block = b;
-    return BBME_OK;
-}
-
-int launch_pass1(bbme_ctx *c, const SweepJob &job, hipStream_t stream)
-{
-    RegArgs a = job.a;
-    // opt-in Jacobi mode, NOT the reference's field: every block against the field as the previous sweep left it, and no more
-    a.flag_cur = nullptr; a.flag_next = c->jacobi ? nullptr : job.flags[0];
-    BBME_BY_BLOCK(job.b, (launch_pass1_t<BS>(a, c->jacobi, c->pass1_lanes_max, (unsigned)c->batch, stream)))
-    HIP_TRY(hipGetLastError());
-    return BBME_OK;
-}
-
-int launch_relax(bbme_ctx *c, const SweepJob &job, hipStream_t stream)
-{
-    for (int i = 0; i < job.steps; ++i) {
-        RegArgs a = job.a;
-        a.flag_cur = job.flags[i & 1]; a.flag_next = job.flags[(i & 1) ^ 1];
-        BBME_BY_BLOCK(job.b, (launch_relax_t<BS>(a, (unsigned)c->batch, stream)))
-    }
-    HIP_TRY(hipGetLastError());
-    return BBME_OK;
-}
-
-// `next`: the sweep whose pass 1 runs (or has run) on this sweep's estimates before this solver has finished -- its dirty map
-// receives the late marks (RegArgs::late_flags); nullptr: none
-int launch_solve(bbme_ctx *c, const SweepJob &job, const SweepJob *next, hipStream_t stream)
-{
-    if (c->jacobi) return BBME_OK;
-    RegArgs a = job.a;
-    a.flag_cur = job.flags[job.steps & 1]; a.flag_next = nullptr;
-    if (next) { a.late_flags = next->flags[0]; a.late_rows = next->a.rows; a.late_cols = next->a.cols; }
-    BBME_BY_BLOCK(job.b, (launch_solve_t<BS>(a, c->solve_wgs, c->solve_waves, c->scan_fine_max, (unsigned)c->batch, stream)))
-    HIP_TRY(hipGetLastError());
-    return BBME_OK;
-}
-
-// the solver of `job` with pass 1 of `next` in the same launch; `next`'s dirty map receives the late marks
-int launch_solve_ahead(bbme_ctx *c, const SweepJob &job, const SweepJob &next, hipStream_t stream)
-{
-    RegArgs a = job.a, n = next.a;
-    a.flag_cur = job.flags[job.steps & 1]; a.flag_next = nullptr;
-    a.late_flags = next.flags[0]; a.late_rows = next.a.rows; a.late_cols = next.a.cols;
-    n.flag_cur = nullptr; n.flag_next = next.flags[0];
-    BBME_BY_BLOCK(job.b, (launch_solve_ahead_t<BS>(a, n, c->solve_wgs, c->scan_fine_max, c->pass1_lanes_max, (unsigned)c->batch, stream)))
-    HIP_TRY(hipGetLastError());
-    return BBME_OK;
-}
-
-int launch_sweep(bbme_ctx *c, int level, int b, int mult)
-{
-    SweepJob job;
-    if (int rc = prepare_sweep(c, level, b, mult, job)) return rc;
-    if (int rc = launch_pass1(c, job, c->stream)) return rc;
-    if (int rc = launch_relax(c, job, c->stream)) return rc;
-    return launch_solve(c, job, nullptr, c->stream);
-}
-
-// All sweeps of a level (while (block_size > 1) :141, lambda_multiplier 1 and 2 :145).  With the look-ahead, pass 1 of the first
-// sweep at half the block size runs in the launch of the solver of the second sweep at the current size (k_reg_solve_ahead), on
-// that sweep's estimates as they stand; the solver marks for re-evaluation whatever that pass 1 read too early (late marks).
-// Second sweeps change little, so the marks are few; the field is the same, bit for bit.
-// `after_own_size`: called once the two sweeps at the level's own block size are enqueued (the speculative search forks there).
-template <class F>
-int enqueue_level_sweeps(bbme_ctx *c, int level, bool lookahead, F after_own_size)
-{
-    Level &L = c->lv[level];
-    std::vector<std::pair<int, int>> sweeps;
-    for (int b = L.block; b > 1; b >>= 1) { sweeps.emplace_back(b, 1); sweeps.emplace_back(b, 2); }
-    SweepJob cur, next;
-    bool have = false;                                     // `cur` is prepared and its pass 1 enqueued already
-    for (size_t i = 0; i < sweeps.size(); ++i) {
-        if (!have) {
-            if (int rc = prepare_sweep(c, level, sweeps[i].first, sweeps[i].second, cur)) return rc;
-            if (int rc = launch_pass1(c, cur, c->stream)) return rc;
-        }
-        if (int rc = launch_relax(c, cur, c->stream)) return rc;
-        have = false;
-        const bool ahead = lookahead && !c->jacobi && c->solve_waves == 4 && i + 1 < sweeps.size() && sweeps[i].second == 2 &&
-                           sweeps[i].first >= 4 && sweeps[i].first <= 32;                                     // next: (b / 2, 1)
-        if (ahead) {
-            if (int rc = prepare_sweep(c, level, sweeps[i + 1].first, sweeps[i + 1].second, next)) return rc;
-            if (int rc = launch_solve_ahead(c, cur, next, c->stream)) return rc;
-            cur = next; have = true;
-        } else if (int rc = launch_solve(c, cur, nullptr, c->stream)) return rc;
-        if (sweeps[i].first == L.block && sweeps[i].second == 2) { if (int rc = after_own_size()) return rc; }
-    }
     return BBME_OK;
 }
 
@@ -551,7 +421,6 @@ int enqueue_pyramid(bbme_ctx *c, bool speculate)
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIP_TRY(hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, lo));
     }
-    const bool lookahead = c->lookahead && !c->jacobi;
     bool speculated = false;
     for (int l = nl - 1; l >= 0; --l) {
         if (speculated) {
@@ -559,17 +428,17 @@ int enqueue_pyramid(bbme_ctx *c, bool speculate)
             if (int rc = launch_search(c, l, kSearchFixup)) return rc;
         } else if (int rc = launch_search(c, l)) return rc;
         speculated = false;
-        auto fork_search = [&]() -> int {
-            if (speculate && l > 0 && c->lv[l].block > 2 && worth_speculating(c, l - 1)) {
+        for (int b = c->lv[l].block; b > 1; b >>= 1) {            // while (block_size > 1) :141
+            for (int mult = 1; mult <= 2; ++mult)                  // lambda_multiplier = l + 1 :145
+                if (int rc = launch_sweep(c, l, b, mult)) return rc;
+            if (speculate && l > 0 && b == c->lv[l].block && b > 2 && worth_speculating(c, l - 1)) {
                 HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
                 HIP_TRY(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
                 if (int rc = launch_search(c, l - 1, kSearchSpeculative, c->side_stream, c->spec_lds)) return rc;
                 HIP_TRY(hipEventRecord(c->ev_join, c->side_stream));
                 speculated = true;
             }
-            return BBME_OK;
-        };
-        if (int rc = enqueue_level_sweeps(c, l, lookahead, fork_search)) return rc;
+        }
     }
     return launch_expand(c);
 }
@@ -665,7 +534,6 @@ int bbme_create_batch(const bbme_params *params, int width, int height, int devi
     if (const char *e = getenv("BBME_SEARCH_SPLIT_BLOCKS")) { c->split_blocks = std::max(0, atoi(e)); c->split_forced = true; }
     if (const char *e = getenv("BBME_NO_GRAPH")) c->use_graph = atoi(e) == 0;
     if (const char *e = getenv("BBME_SPECULATE")) c->speculate = atoi(e) != 0;
-    if (const char *e = getenv("BBME_LOOKAHEAD")) c->lookahead = atoi(e) != 0;
     {
         // a speculative search may keep at most this many of its (one-wave) workgroups on a CU: the rest of the CU's wave
         // slots, registers and LDS (40 KB) stay free for the regulariser kernels it runs beside
@@ -710,7 +578,6 @@ int bbme_create_batch(const bbme_params *params, int width, int height, int devi
             (err = hipMemset(L.fix_count, 0, P * 64)) != hipSuccess ||
             (err = hipMalloc(&L.big[0], P * cells * sizeof(mv_t))) != hipSuccess ||
             (err = hipMalloc(&L.big[1], P * cells * sizeof(mv_t))) != hipSuccess ||
-            (err = hipMalloc(&L.big[2], P * cells * sizeof(mv_t))) != hipSuccess ||
             (err = hipMalloc(&L.spiral, packed.size() * 4)) != hipSuccess ||
             (err = hipMemset(L.img1, 0, P * plane)) != hipSuccess || (err = hipMemset(L.img2, 0, P * plane)) != hipSuccess ||
             (err = hipMemcpy(L.spiral, packed.data(), packed.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
@@ -762,12 +629,8 @@ int bbme_create_batch(const bbme_params *params, int width, int height, int devi
         (err = hipMalloc(&c->list[1], P * max_blocks * 4)) != hipSuccess ||
         (err = hipMalloc(&c->flags[0], P * c->flag_bytes)) != hipSuccess ||
         (err = hipMalloc(&c->flags[1], P * c->flag_bytes)) != hipSuccess ||
-        (err = hipMalloc(&c->flags[2], P * c->flag_bytes)) != hipSuccess ||
-        (err = hipMalloc(&c->flags[3], P * c->flag_bytes)) != hipSuccess ||
         (err = hipMemset(c->flags[0], 0, P * c->flag_bytes)) != hipSuccess ||
         (err = hipMemset(c->flags[1], 0, P * c->flag_bytes)) != hipSuccess ||
-        (err = hipMemset(c->flags[2], 0, P * c->flag_bytes)) != hipSuccess ||
-        (err = hipMemset(c->flags[3], 0, P * c->flag_bytes)) != hipSuccess ||
         (err = hipMalloc(&c->own, P * bit_words * 4)) != hipSuccess ||
         (err = hipMalloc(&c->counters, P * 256)) != hipSuccess ||
         (err = hipMemset(c->own, 0, P * bit_words * 4)) != hipSuccess ||
@@ -790,7 +653,7 @@ int bbme_destroy(bbme_ctx *c)
         (void)hipFree(L.img1); (void)hipFree(L.img2);
         (void)hipFree(L.small[0]); (void)hipFree(L.small[1]); (void)hipFree(L.pred);
         (void)hipFree(L.fix_list); (void)hipFree(L.fix_count);
-        (void)hipFree(L.big[0]); (void)hipFree(L.big[1]); (void)hipFree(L.big[2]); (void)hipFree(L.spiral);
+        (void)hipFree(L.big[0]); (void)hipFree(L.big[1]); (void)hipFree(L.spiral);
         (void)hipFree(L.rank_of); (void)hipFree(L.tasks); (void)hipFree(L.rounds); (void)hipFree(L.tasks2); (void)hipFree(L.rounds2);
     }
     (void)hipFree(c->flow);
@@ -798,7 +661,7 @@ int bbme_destroy(bbme_ctx *c)
     (void)hipFree(c->raw[0]); (void)hipFree(c->raw[1]);
     (void)hipFree(c->list[0]); (void)hipFree(c->list[1]);
     (void)hipFree(c->own);
-    for (uint8_t *f : c->flags) (void)hipFree(f);
+    (void)hipFree(c->flags[0]); (void)hipFree(c->flags[1]);
     (void)hipFree(c->counters);
     if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -856,17 +719,6 @@ int bbme_set_speculation(bbme_ctx *c, int enabled)
     drop_graph(c);                                   // the launch sequence changes
     c->speculate = enabled != 0;
     if (!c->speculate && c->side_stream) { (void)hipStreamDestroy(c->side_stream); c->side_stream = nullptr; }
-    return BBME_OK;
-}
-
-int bbme_set_lookahead(bbme_ctx *c, int enabled)
-{
-    if (int rc = check_ctx(c)) return rc;
-    if (c->lookahead == (enabled != 0)) return BBME_OK;
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    drop_graph(c);                                   // the launch sequence changes
-    c->lookahead = enabled != 0;
     return BBME_OK;
 }
 
@@ -1245,7 +1097,7 @@ int bbme_last_sweep_passes(bbme_ctx *c, int *passes)
     if (!passes) return bbme::fail(BBME_ERR_INVALID, "null output");
     HIP_TRY(hipSetDevice(c->device));
     uint32_t host[8];
-    HIP_TRY(hipMemcpyAsync(host, c->counters + 16 * c->last_counter_set, sizeof host, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(host, c->counters, sizeof host, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     passes[0] = (int)host[3];
     passes[1] = (int)host[4];
@@ -1258,7 +1110,7 @@ int bbme_sweep_stats(bbme_ctx *c, unsigned *stats)
     if (int rc = check_ctx(c)) return rc;
     if (!stats) return bbme::fail(BBME_ERR_INVALID, "null output");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemcpyAsync(stats, c->counters + 16 * c->last_counter_set, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(stats, c->counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return BBME_OK;
 }

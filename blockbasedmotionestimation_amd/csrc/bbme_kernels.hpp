@@ -751,12 +751,6 @@ struct RegArgs {
                                 // one wave, [8] rounds summed, [9..15] phase profile
     // batch (blockIdx.y = pair): element strides from pair to pair of the per-pair buffers; counters: 64 words
     uint32_t s_plane, s_old, s_est, s_list, s_own, s_flag;
-    // look-ahead: pass 1 of the NEXT sweep (at half this block size) may already be running, or have run, on this sweep's
-    // estimates as they stood; every change this solver makes marks, in that sweep's dirty map, the blocks whose pass 1 read the
-    // changed value (the 4 x 4 children around the changed block: child (i, j) reads parents (i + d) >> 1, d in -1..1), so that
-    // its solver re-evaluates them.  nullptr: no look-ahead.
-    uint8_t *late_flags;
-    int late_rows, late_cols;   // that sweep's grid
 };
 __device__ __forceinline__ void shift_pair(RegArgs &a, uint32_t p)
 {
@@ -766,7 +760,6 @@ __device__ __forceinline__ void shift_pair(RegArgs &a, uint32_t p)
     a.own += (size_t)p * a.s_own;
     if (a.flag_cur) a.flag_cur += (size_t)p * a.s_flag;
     if (a.flag_next) a.flag_next += (size_t)p * a.s_flag;
-    if (a.late_flags) a.late_flags += (size_t)p * a.s_flag;
     a.counters += (size_t)p * 64u;
 }
 
@@ -1163,20 +1156,13 @@ __device__ __forceinline__ void mark_dependants(const RegArgs &a, uint8_t *flags
     }
 }
 
-// look-ahead (RegArgs::late_flags): block (r, c) of this sweep has a new estimate; `part` in 0..15 names one of the 4 x 4 blocks
-// of the next sweep's (twice as fine) grid whose pass 1 read it.  Idempotent byte stores, consumed by a later launch.
-__device__ __forceinline__ void late_mark_child(const RegArgs &a, int r, int c, int part)
-{
-    const int i = 2 * r - 1 + (part >> 2), j = 2 * c - 1 + (part & 3);
-    if (i >= 0 && i < a.late_rows && j >= 0 && j < a.late_cols) a.late_flags[(size_t)i * a.late_cols + j] = 1;
-}
-
-// (the bodies take the workgroup's index as an argument: k_reg_solve_ahead runs pass 1 in the workgroups behind the solver's)
 template <int BS>
-__device__ __forceinline__ void pass1_body(const RegArgs &a, uint32_t wg)
+__global__ __launch_bounds__(256) void k_reg_pass1(RegArgs a)
 {
     constexpr int LPB = RegCfg<BS>::LPB;
-    const long long t = (long long)wg * 256 + threadIdx.x;
+    __builtin_amdgcn_s_setprio(2);                 // latency-bound: ahead of a speculative search sharing the SIMD
+    shift_pair(a, blockIdx.y);
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     // the solver's counters (nothing else touches them before this sweep's solver launch)
     if (t < 16 && t != 5) a.counters[t] = 0;
     const long long g = t / LPB;
@@ -1227,14 +1213,6 @@ __device__ __forceinline__ void pass1_body(const RegArgs &a, uint32_t wg)
     }
 }
 
-template <int BS>
-__global__ __launch_bounds__(256) void k_reg_pass1(RegArgs a)
-{
-    __builtin_amdgcn_s_setprio(2);                 // latency-bound: ahead of a speculative search sharing the SIMD
-    shift_pair(a, blockIdx.y);
-    pass1_body<BS>(a, blockIdx.x);
-}
-
 // Relaxation over the marked blocks, the whole chip at once, before the solver.  The grid is cut into tiles of
 // T x T blocks, one workgroup each.  A workgroup keeps the estimates of its tile (+ the ring of neighbours it reads:
 // one column left and right, one row above) in LDS, evaluates the marked blocks of the tile, and when a block
@@ -1245,9 +1223,11 @@ __global__ __launch_bounds__(256) void k_reg_pass1(RegArgs a)
 // Pass 1 in the chain form (16 lanes per block, lane k = candidate k), for grids too small to fill the chip: there the launch
 // lasts as long as one wave's instruction stream does, and the chain form's is a third as long as eval_block's.
 template <int BS>
-__device__ __forceinline__ void pass1_lanes_body(const RegArgs &a, uint32_t wg)
+__global__ __launch_bounds__(256) void k_reg_pass1_lanes(RegArgs a)
 {
-    const long long t = (long long)wg * 256 + threadIdx.x;
+    __builtin_amdgcn_s_setprio(2);
+    shift_pair(a, blockIdx.y);
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t < 16 && t != 5) a.counters[t] = 0;                  // as k_reg_pass1
     const long long g = t >> 4;
     const int k16 = (int)(t & 15);
@@ -1259,14 +1239,6 @@ __device__ __forceinline__ void pass1_lanes_body(const RegArgs &a, uint32_t wg)
         const mv_t old = a.old_grid[(size_t)(r >> a.old_shift) * a.old_cols + (c >> a.old_shift)];
         if (a.flag_next && res != old) mark_dependants(a, a.flag_next, r, c);
     }
-}
-
-template <int BS>
-__global__ __launch_bounds__(256) void k_reg_pass1_lanes(RegArgs a)
-{
-    __builtin_amdgcn_s_setprio(2);
-    shift_pair(a, blockIdx.y);
-    pass1_lanes_body<BS>(a, blockIdx.x);
 }
 
 // This is asynchronous fixed-point iteration: any number of rounds or launches, followed by k_reg_solve, ends at
@@ -1416,9 +1388,7 @@ __device__ __forceinline__ void drain_lists(const RegArgs &a, int t, int nthread
             if (sub == 0) own_release(a, x);                                  // the list owned it
             BBME_DRAIN();
             const mv_t res = eval_block_lanes<BS, true>(a, r, c, sub, BBME_NEW_MASK);
-            const bool moved = sub == 0 && res != load_est<true>(a.est + x);
-            if (a.late_flags && dpp_row<0x150>((uint32_t)moved)) late_mark_child(a, r, c, sub);      // the group's 16 lanes, one child each
-            if (moved) {
+            if (sub == 0 && res != load_est<true>(a.est + x)) {
                 __hip_atomic_store(a.est + x, res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 BBME_DRAIN();
                 const int dr[4] = {0, 1, 1, 1}, dc[4] = {1, 1, 0, -1};
@@ -1454,8 +1424,8 @@ __device__ __forceinline__ void drain_lists(const RegArgs &a, int t, int nthread
 // s belongs to wave s mod W of that XCD, so that a cluster of stale blocks is spread over many waves
 // instead of queueing up behind one, and a wave looks at 64 of its segments -- 1024 flags -- per memory
 // trip: a sweep that left nothing stale costs two trips at 2 M blocks, not 127.
-template <int BS, int SEG>
-__device__ __forceinline__ void solve_body(const RegArgs &a, const uint32_t wg, const uint32_t nwg)
+template <int BS, int SEG = 16>
+__global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
 {
     static_assert(SEG == 16 || SEG == 4, "flags per scan segment");
     // two forms of a round: WIDE (eval_block: LPBW lanes per block, 64/LPBW blocks per round) when
@@ -1467,13 +1437,15 @@ __device__ __forceinline__ void solve_body(const RegArgs &a, const uint32_t wg, 
     constexpr uint32_t QCAP = 1024;
     __shared__ uint32_t qmem[4][QCAP];
     __shared__ uint32_t s_ticket;
+    __builtin_amdgcn_s_setprio(2);
+    shift_pair(a, blockIdx.y);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint32_t *q = qmem[wave];
     const uint32_t nblocks = (uint32_t)a.rows * a.cols;
-    const uint32_t xcd = wg & 7u;                          // the solver has a multiple of 8 workgroups
+    const uint32_t xcd = blockIdx.x & 7u;                  // the launch has a multiple of 8 workgroups
     const uint32_t wpw = blockDim.x >> 6;                  // waves per workgroup (1, 2 or 4)
-    const uint32_t wx = (wg >> 3) * wpw + wave, Wx = (nwg >> 3) * wpw;
+    const uint32_t wx = (blockIdx.x >> 3) * wpw + wave, Wx = (gridDim.x >> 3) * wpw;
     const uint32_t nseg = (nblocks + (uint32_t)SEG - 1u) / (uint32_t)SEG, band = (nseg + 7u) / 8u;
     const uint32_t seg_begin = min(xcd * band, nseg), seg_end = min(seg_begin + band, nseg);
     uint32_t *ovf_list = a.list0;
@@ -1562,13 +1534,6 @@ __device__ __forceinline__ void solve_body(const RegArgs &a, const uint32_t wg, 
                 else res = eval_block_lanes<BS, true>(a, r, c, sub, BBME_NEW_MASK, prof, &lgeom);
                 changed = leader && res != prev;
                 if (changed) __hip_atomic_store(a.est + x, res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (a.late_flags) {
-                    if (!wide) {
-                        if (dpp_row<0x150>((uint32_t)changed)) late_mark_child(a, r, c, sub);     // the group's 16 lanes, one child each
-                    } else if (changed) {
-                        for (int part = 0; part < 16; ++part) late_mark_child(a, r, c, part);
-                    }
-                }
             }
             evaluated += cnt;
             if (__ballot(changed)) BBME_DRAIN();                       // the stores have completed
@@ -1657,35 +1622,8 @@ __device__ __forceinline__ void solve_body(const RegArgs &a, const uint32_t wg, 
     __syncthreads();
     if (threadIdx.x == 0) s_ticket = atomicAdd(&a.counters[6], 1u);
     __syncthreads();
-    if (s_ticket != nwg - 1) return;
+    if (s_ticket != gridDim.x - 1) return;
     drain_lists<BS>(a, threadIdx.x, (int)blockDim.x);
-}
-
-template <int BS, int SEG = 16>
-__global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
-{
-    __builtin_amdgcn_s_setprio(2);
-    shift_pair(a, blockIdx.y);
-    solve_body<BS, SEG>(a, blockIdx.x, gridDim.x);
-}
-
-// Look-ahead (RegArgs::late_flags): the solver of a sweep and, in the workgroups behind the solver's, pass 1 of the next sweep (at
-// half the block size) on this sweep's estimates as they stand -- one launch instead of two, and the chip-wide pass 1 fills the
-// chip the latency-bound solver leaves idle.  No ordering between the two roles is needed: whatever pass 1 reads before the
-// solver changes it is marked for re-evaluation by the change (late_mark_child), and pass 1 touches nothing the solver reads.
-template <int BS, int SEG, bool LANES>
-__global__ __launch_bounds__(256) void k_reg_solve_ahead(RegArgs a, RegArgs n, uint32_t solve_wgs)
-{
-    static_assert(BS >= 4, "the next sweep works at half the block size");
-    __builtin_amdgcn_s_setprio(2);
-    if (blockIdx.x < solve_wgs) {                             // workgroup-uniform
-        shift_pair(a, blockIdx.y);
-        solve_body<BS, SEG>(a, blockIdx.x, solve_wgs);
-    } else {
-        shift_pair(n, blockIdx.y);
-        if constexpr (LANES) pass1_lanes_body<BS / 2>(n, blockIdx.x - solve_wgs);
-        else pass1_body<BS / 2>(n, blockIdx.x - solve_wgs);
-    }
 }
 
 // =======================================================================================

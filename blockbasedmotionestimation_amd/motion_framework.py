@@ -108,10 +108,6 @@ class MF:
         Turn them off, like the speculation, when several pairs are in flight on the GPU."""
         _capi.check(self._lib.bbme_set_relaxation(self._ctx, 1 if enabled else 0))
 
-    def set_lookahead(self, enabled):
-        """Scheduling only (same field): pass 1 of the next block size's first sweep beside the solver before it."""
-        _capi.check(self._lib.bbme_set_lookahead(self._ctx, 1 if enabled else 0))
-
     def set_stream(self, hip_stream_handle):
         _capi.check(self._lib.bbme_set_stream(self._ctx, C.c_void_p(hip_stream_handle)))
 

@@ -185,11 +185,6 @@ int bbme_set_speculation(bbme_ctx *ctx, int enabled);
  * bit for bit.  Turn it off, like the speculation, when several contexts keep the chip busy (8 pairs in flight at 4K:
  * 31.6 -> 33.2 Mblocks/s). */
 int bbme_set_relaxation(bbme_ctx *ctx, int enabled);
-/* Scheduling option (default on; BBME_LOOKAHEAD=0 turns the default off): pass 1 of the first sweep at half the block size
- * runs in the launch of the (latency-bound) solver of the second sweep at the current size -- one launch fewer per block size,
- * the chip-wide pass 1 in the shadow of the solver -- working on that sweep's estimates as they stand; the solver marks
- * whatever that pass 1 read too early for re-evaluation.  Same field, bit for bit. */
-int bbme_set_lookahead(bbme_ctx *ctx, int enabled);
 /* Orders the ctx stream behind everything enqueued so far on another HIP stream of the same device (NULL = the default
  * stream): call it before bbme_set_frames_device when the frames were produced by asynchronous work on that stream.
  * Without it the caller must have synchronised the producer itself. */
