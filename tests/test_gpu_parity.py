@@ -572,6 +572,14 @@ def test_batched_context_matches_the_oracle_pair_by_pair(bbme, oracle, w, h, sea
     with pytest.raises(bbme.BbmeError):
         mb.get_pair_flow(4)
     mb.close()
+    # frames already in HBM (torch tensors), as bench.py's sequence leg hands them over
+    import torch
+    dev = [(torch.from_numpy(f1).cuda(), torch.from_numpy(f2).cuda()) for f1, f2 in pairs[:3]]
+    mb = bbme.MFBatch(dev, ss, bs, levels, frames_on_device=True)
+    got = mb.calcMotionBlockMatching()
+    mb.close()
+    for p in range(3):
+        assert np.array_equal(got[p], exp[p]), "pair %d (device frames)" % p
 
 
 @pytest.mark.parametrize("cfg", ["cfg2_1080p", "cfg3_4k", "cfg4_4k_b8"])
