@@ -67,6 +67,26 @@ def pmc_traffic(levels):
     return None
 
 
+def pmc_sq_summary():
+    """The SQ-counter summary of the level-0 search launch from the committed rocprofv3 --pmc passes (profiles/rNN_pmc_search_sq.json,
+    scripts/pmc_search.sh + pmc_search_report.py): VALU busy, instruction mix, LDS conflicts, waits.  Only quoted when measured on
+    exactly this kernel source."""
+    import glob
+    import hashlib
+    src = os.path.join(ROOT, "blockbasedmotionestimation_amd", "csrc", "bbme_kernels.hpp")
+    digest = hashlib.sha256(open(src, "rb").read()).hexdigest()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_search_sq.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            if d.get("kernel_source_sha256") == digest and "summary_level0_launch" in d:
+                out = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in d["summary_level0_launch"].items()}
+                out["source"] = os.path.relpath(path, ROOT)
+                return out
+        except (OSError, ValueError, KeyError):
+            pass
+    return None
+
+
 def epe_on_ground_truth(bbme, device, jacobi=False):
     """Average end-point error of the reference's own pipeline and literals (4x bilinear up-sampling, 4
     levels, block 32, search 64, every 4th pixel / 4; main_class.cpp:19-21,32-33,58-70) against Middlebury
@@ -515,6 +535,7 @@ def main():
                                      "frac_of_qsad_strip_loop": round(tabs / loops[0], 5),
                                      "level0_launch": {"ms": round(prof["search_level0_ms"], 4),
                                                        "achieved": round(blocks[0] * (2 * R + 1) ** 2 * block * block / (prof["search_level0_ms"] * 1e-3) / 1e12, 3)}},
+                         "sq_counters_level0_launch": pmc_sq_summary(),
                          "xcd_round_robin": xcd_check},
             "search_only": {"value": round(sum(blocks) / (prof["search_ms"] * 1e-3) / 1e6, 3), "unit": "Mblocks/s",
                             "blocks": sum(blocks), "ms": round(prof["search_ms"], 4),

@@ -57,6 +57,27 @@ for key in sorted(acc, key=lambda k: -k[1]):
     if "SQ_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
         d["sq_busy_over_gui_active"] = c["SQ_BUSY_CYCLES"] / c["GRBM_GUI_ACTIVE"]
     out["%s grid=%d" % (short, grid)] = d
+# the figures bench.py quotes for the level-0 launch (the largest grid): VALU busy = SQ_ACTIVE_INST_VALU (quad-cycles, summed over
+# waves) x 4 / 1024 SIMDs against the launch's GRBM_GUI_ACTIVE / 8 XCDs
+import hashlib
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = open(os.path.join(ROOT, "blockbasedmotionestimation_amd", "csrc", "bbme_kernels.hpp"), "rb").read()
+big = max(out.values(), key=lambda v: v["grid_threads"]) if out else None
+if big and "SQ_ACTIVE_INST_VALU" in big["counters"] and "GRBM_GUI_ACTIVE" in big["counters"]:
+    c = big["counters"]
+    cyc = c["GRBM_GUI_ACTIVE"] / 8.0
+    out["summary_level0_launch"] = {
+        "kernel_cycles_per_xcd": cyc,
+        "valu_busy": c["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / cyc,
+        "valu_insts_per_wave": big.get("per_wave:SQ_INSTS_VALU"), "salu_insts_per_wave": big.get("per_wave:SQ_INSTS_SALU"),
+        "lds_insts_per_wave": big.get("per_wave:SQ_INSTS_LDS"), "vmem_insts_per_wave": big.get("per_wave:SQ_INSTS_VMEM"),
+        "lds_bank_conflict_share_of_lds_cycles": big.get("lds_bank_conflict_share_of_lds_cycles"),
+        "wave_cycles_waiting_to_issue": big.get("share_of_wave_cycles:SQ_WAIT_INST_ANY"),
+        "wave_cycles_waiting_on_lds_issue": big.get("share_of_wave_cycles:SQ_WAIT_INST_LDS"),
+        "wave_cycles_parked": big.get("share_of_wave_cycles:SQ_WAIT_ANY"),
+        "waves": c.get("SQ_WAVES"), "mean_waves_per_simd": c.get("SQ_WAVE_CYCLES", 0) * 4.0 / 1024.0 / cyc,
+    }
+out["kernel_source_sha256"] = hashlib.sha256(src).hexdigest()
 print(json.dumps(out, indent=1, sort_keys=True))
 if a.json:
     json.dump(out, open(a.json, "w"), indent=1, sort_keys=True)
