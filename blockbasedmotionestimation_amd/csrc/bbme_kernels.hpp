@@ -648,7 +648,7 @@ __device__ __forceinline__ void search_block_fast(const FastSearchArgs &a, uint3
 }
 
 template <int B, int W>
-__global__ __launch_bounds__(64 * W) void k_search_fast(FastSearchArgs a)
+__global__ __launch_bounds__(64 * W, (W == 1 && B <= 16 ? 5 : 1)) void k_search_fast(FastSearchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     shift_pair(a, blockIdx.y);
@@ -692,8 +692,10 @@ __global__ __launch_bounds__(256) void k_fixup_list(FastSearchArgs a, int block,
     if (redo) list[s_base + slot] = bid;
 }
 
+// (five waves per SIMD, 96 registers: a fix-up list of ~5 000 blocks at 4K then fits the chip's 5 120 wave slots in ONE generation instead
+// of a full one and a nearly empty one -- 64 -> 4x us at level 0)
 template <int B>
-__global__ __launch_bounds__(64) void k_search_list(FastSearchArgs a, const uint32_t *count, const uint32_t *list)
+__global__ __launch_bounds__(64, (B <= 16 ? 5 : 1)) void k_search_list(FastSearchArgs a, const uint32_t *count, const uint32_t *list)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     shift_pair(a, blockIdx.y);
@@ -1774,11 +1776,13 @@ __global__ __launch_bounds__(256) void k_pyr_down4(PlanePair p, int sw, int sh)
     const uint32_t wy[5] = {1, 4, 6, 4, 1};
 #pragma unroll
     for (int ky = 0; ky < 5; ++ky) {
-        const uint32_t *row = reinterpret_cast<const uint32_t *>(src + (size_t)mirror101(2 * y + ky - 2, sh) * sw + 8 * k);
+        // the four dwords around input byte 8k in ONE 16-byte load (any byte alignment is fine on gfx950): a quarter of the load
+        // instructions of four dword loads.  The first thread of a row starts at the row itself (nothing may be read in front of
+        // the plane); the last one reads up to 4 bytes past the row (the next row, or the plane's slack) and ignores them.
+        const uint8_t *row = src + (size_t)mirror101(2 * y + ky - 2, sh) * sw + 8 * k;
+        const ua_u128 v = *reinterpret_cast<const ua_u128 *>(row - (left ? 0 : 4));
         uint32_t d[4];
-        d[1] = row[0]; d[2] = row[1];                                   // input bytes 8k .. 8k+7: always inside the row
-        d[0] = left ? 0u : row[-1];
-        d[3] = right ? 0u : row[2];
+        d[0] = v.v[0]; d[1] = left ? v.v[0] : v.v[1]; d[2] = left ? v.v[1] : v.v[2]; d[3] = left ? v.v[2] : v.v[3];
         // BORDER_REFLECT_101 at the row ends, without divergent byte loops: of d[0] only input bytes -2, -1 (= 2, 1) are
         // used, of d[3] only input byte 8k+8 (= sw, mirrored to sw - 2 = 8k+6)
         if (left) d[0] = (d[1] & 0x00ff0000u) | (d[1] & 0x0000ff00u) << 16;
