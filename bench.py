@@ -314,7 +314,31 @@ def main():
         # an explicit stream: torch's default stream has handle 0, which bbme_set_stream reads as "create a private stream"
         work_stream = torch.cuda.Stream(device=local_rank)
         torch.cuda.set_stream(work_stream)
-        gather = mf_cell_gather(mf, local_rank)
+        # Two pairings of the context's graph with the gather (sequence.CellGather): the speculative graph with gather and
+        # expansions in order on its stream, or the plain graph with gather and expansions on a second stream beside the
+        # next estimate -- a second stream waiting behind the forked (speculative) graph costs more than it hides
+        # (scripts/dist_step_probe.py).  Both give the same fields; which is faster depends on N (the gather and rank 0's N
+        # expansions grow with it), so both are timed here, before the timed region, and every rank keeps the faster.
+        dist_modes = [("speculative graph; gather and expansions in order on its stream", True, False),
+                      ("plain graph; gather and expansions on a second stream beside the next estimate", False, True)]
+        dist_calibration = []
+        for text, spec, overlap in dist_modes:
+            mf.set_speculation(spec)
+            cand = mf_cell_gather(mf, local_rank, overlap=overlap)
+            for _ in range(3):
+                cand.step()
+            cand.fence(); mf.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                cand.step()
+            cand.fence(); mf.synchronize()
+            t = torch.tensor([(time.perf_counter() - t0) / 10 * 1e3], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist_calibration.append((float(t.item()), text, spec, overlap))
+            del cand
+        _, dist_mode_text, spec, overlap = min(dist_calibration)        # all-reduced times: the same choice on every rank
+        mf.set_speculation(spec)
+        gather = mf_cell_gather(mf, local_rank, overlap=overlap)
 
     def step():
         if gather is None:
@@ -514,8 +538,10 @@ def main():
                        "block": block, "search_range": R, "levels": levels,
                        "blocks_level0": blocks[0], "blocks_all_levels": sum(blocks),
                        "multi_gpu": ("one pair per GPU; int16 cell grids gathered on rank 0 over RCCL and expanded there to "
-                                     "the dense .flo fields, on a second stream beside the next step's estimate")
-                                    if world > 1 else "single GPU"},
+                                     "the dense .flo fields (" + dist_mode_text + "; ms per step measured before the timed "
+                                     "region: " + ", ".join("%.3f %s" % (t, "speculative" if sp else "plain/overlapped")
+                                                            for t, _, sp, _ in dist_calibration) + ")")
+                                    if use_dist else "single GPU"},
             # contract fields (achieved / peak / unit / frac / traffic) are the HBM figures; what BINDS the kernel is the issue
             # rate of the integer SAD instructions, priced in `binding` against the chip's spec rate
             "roofline": {"bound": "valu", "kernel": "k_search_fast<%d, W> (mean of the %d per-level launches; W = 2 waves per macroblock on levels of "

@@ -54,17 +54,22 @@ class CellGather:
     cells                      torch int32 tensor (rows, cols) the estimate leaves its result in
     expand(words, flow, strm)  rank 0: one gathered grid -> dense (2*rows, 2*cols, 2) float32 tensor `flow`;
                                strm = raw HIP stream handle the expansion must run on (None on the CPU)
-    On a GPU the gather of step i and rank 0's expansions run on a second stream beside the estimate of step i + 1:
-    each step copies its grid into one of two staging buffers; events order the two streams.  `flows` (rank 0) holds
-    the dense fields of the last finished step, one per rank.
+    On a GPU, with `overlap` (default), the gather of step i and rank 0's expansions run on a second stream beside the
+    estimate of step i + 1: each step copies its grid into one of two staging buffers; events order the two streams.
+    With overlap=False the estimate, the gather and the expansions are simply enqueued in order on the work stream.  That is
+    the better form when the estimate is a hipGraph with a forked branch (the speculative search): a second stream waiting
+    for an event recorded behind such a graph costs the next replay about 0.7 ms on ROCm 7 (scripts/dist_step_probe.py:
+    1.75 -> 2.45 ms per 4K step), far more than the ~0.1 ms of gather and expansions it would hide.  bench.py measures
+    both pairings before the timed region and keeps the faster.  `flows` (rank 0) holds the dense fields of the last
+    finished step, one per rank.
     """
 
-    def __init__(self, estimate, cells, expand, group=None, dst=0):
+    def __init__(self, estimate, cells, expand, group=None, dst=0, overlap=True):
         import torch
         import torch.distributed as dist
         self._dist, self._torch = dist, torch
         self.estimate, self.cells, self.expand = estimate, cells, expand
-        self.group, self.dst = group, dst
+        self.group, self.dst, self.overlap = group, dst, overlap
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.on_gpu = cells.is_cuda
@@ -92,6 +97,14 @@ class CellGather:
                 for r in range(self.world):
                     self.expand(self.gather_list[r], self.flows[r], None)
             return
+        if not self.overlap:
+            self.estimate()
+            with torch.cuda.stream(self.work_stream):
+                dist.gather(self.cells, self.gather_list, dst=self.dst, group=self.group)
+                if self.rank == self.dst:
+                    for r in range(self.world):
+                        self.expand(self.gather_list[r], self.flows[r], self.work_stream.cuda_stream)
+            return
         self.work_stream.wait_event(self.ev_free[b])      # the gather that read this staging buffer two steps ago is done
         self.estimate()
         with torch.cuda.stream(self.work_stream):
@@ -113,7 +126,7 @@ class CellGather:
         self._dist.barrier(group=self.group)
 
 
-def mf_cell_gather(mf, device, group=None):
+def mf_cell_gather(mf, device, group=None, overlap=True):
     """CellGather over a context (MF) whose frames are set: the estimate, the context's cell grid and
     bbme_expand_cells_device_on.  The context is moved onto torch's current stream, which must not be the default
     stream (handle 0 means "private stream" to bbme_set_stream)."""
@@ -132,7 +145,7 @@ def mf_cell_gather(mf, device, group=None):
 
     def expand(words, flow, strm):
         mf.expand_cells_device(words.data_ptr(), flow.data_ptr(), strm)
-    return CellGather(mf.estimate_async, cells, expand, group=group)
+    return CellGather(mf.estimate_async, cells, expand, group=group, overlap=overlap)
 
 
 def shard_pairs(n_pairs, rank, world_size):

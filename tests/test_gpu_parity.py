@@ -612,11 +612,13 @@ def test_full_size_properties(bbme, cfg):
     mf.close()
 
 
-def test_cell_gather_world_size_one_nccl(bbme, oracle):
+@pytest.mark.parametrize("overlap,speculate", [(True, False), (False, True), (True, True)],
+                         ids=["second_stream", "in_order_speculative", "second_stream_speculative"])
+def test_cell_gather_world_size_one_nccl(bbme, oracle, overlap, speculate):
     """The multi-GPU step (sequence.CellGather / mf_cell_gather, what `bench.py --gpus N` runs) on the one GPU of this
-    box with an RCCL process group of size one: estimate on the work stream, cell grid staged, gathered and expanded
-    with the expand kernel on the side stream.  Three steps (both staging buffers, overlap of gather and next
-    estimate); rank 0's dense field must be the oracle's."""
+    box with an RCCL process group of size one: estimate on the work stream, then either the cell grid staged, gathered and
+    expanded with the expand kernel on the side stream (three steps: both staging buffers, overlap of gather and next
+    estimate) or gather and expansion in order on the work stream; rank 0's dense field must be the oracle's."""
     import os
     import socket
     import torch
@@ -630,11 +632,12 @@ def test_cell_gather_world_size_one_nccl(bbme, oracle):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         mf = bbme.MF(f1, f2, search, block, 3)
+        mf.set_speculation(speculate)
         for lvl in range(3):
             mf.set_level_planes(lvl, omf.image(lvl, 1), omf.image(lvl, 2))
         exp = omf.calc_motion_block_matching()
         with torch.cuda.stream(torch.cuda.Stream(device=0)):
-            g = mf_cell_gather(mf, 0)
+            g = mf_cell_gather(mf, 0, overlap=overlap)
             for _ in range(3):
                 g.step()
             g.fence()
