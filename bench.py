@@ -39,6 +39,8 @@ WORKLOADS = {
     "ref": (2336, 1552, 64, 32, 4, "reference literals (main_class.cpp:19-21): 584x388 frame up-sampled x4, 32x32 blocks, "
                                    "search 64 (+-16), 4 levels"),
 }
+# pairs in flight of the `sequence_deep` legs (4 batched contexts): small frames are launch-bound, so they take deeper batches
+DEEP_SEQUENCE = {"cfg1": 64, "cfg2": 32, "cfg4": 24, "ref": 32}
 
 
 def level_blocks(pw, ph, block, levels):
@@ -251,6 +253,34 @@ def other_workload(bbme, torch, name, device, steps, warmup, check):
         c.close()
     out["sequence_8_pairs"] = {"value": round(blocks[0] / dts / 1e6, 4), "unit": "Mblocks/s", "ms_per_pair": round(dts * 1e3, 4),
                                "contexts": 4, "pairs_per_context": 2, "first_pair_field_unchanged": same}
+    # a longer sequence on the same four streams: more pairs per batched context (the same eight pairs rolled by a few pixels)
+    deep = DEEP_SEQUENCE.get(name, 0)
+    if deep > 8:
+        per = deep // 4
+        while len(frames) < deep:
+            k = len(frames)
+            sh = (3 * (k // 8), 5 * (k // 8))
+            frames.append((torch.roll(frames[k % 8][0], sh, (0, 1)).contiguous(), torch.roll(frames[k % 8][1], sh, (0, 1)).contiguous()))
+        ctxs = [bbme.MFBatch(frames[per * i:per * (i + 1)], [search] * levels, [block] * levels, levels, device=device,
+                             frames_on_device=True) for i in range(4)]
+        for c in ctxs:
+            c.set_speculation(False)
+            c.estimate_async()
+        for c in ctxs:
+            c.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            for c in ctxs:
+                c.estimate_async()
+        for c in ctxs:
+            c.synchronize()
+        dts = (time.perf_counter() - t0) / (steps * deep)
+        same = bool(np.array_equal(ctxs[0].get_pair_flow(0), flow))
+        for c in ctxs:
+            c.close()
+        out["sequence_deep"] = {"pairs_in_flight": deep, "value": round(blocks[0] / dts / 1e6, 4), "unit": "Mblocks/s",
+                                "ms_per_pair": round(dts * 1e3, 4), "contexts": 4, "pairs_per_context": per,
+                                "first_pair_field_unchanged": same}
     return out
 
 
@@ -267,8 +297,11 @@ def main():
                     help="skip the host_boundary legs (for kernel traces: their pyramids start from freshly uploaded frames)")
     ap.add_argument("--in-flight", type=int, default=8,
                     help="N=1 only: also report the throughput of a sequence with this many independent pairs in flight "
-                         "(one context and stream per pair); 0 = skip.  Reported beside `value`, never as `value`")
+                         "(batched contexts of --seq-batch pairs); 0 = skip.  Reported beside `value`, never as `value`")
     ap.add_argument("--seq-batch", type=int, default=2, help="pairs per batched context in the `sequence` leg")
+    ap.add_argument("--in-flight-deep", type=int, default=24,
+                    help="N=1 only: a second sequence leg with this many pairs in flight, as 4 batched contexts (`sequence_deep`); "
+                         "0 = skip")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal on one GPU: run the N>1 code path (process group, gather, expand) with world size 1")
     args = ap.parse_args()
@@ -373,43 +406,57 @@ def main():
     # a sequence on one GPU: K independent pairs in flight, one context (and private stream) each.
     # One pair leaves most of the chip idle while the regulariser walks its dependency chains, so
     # pairs of a sequence overlap well.  Reported as `sequence`, beside the single-pair `value`.
-    sequence = None
+    sequence = sequence_deep = None
     if rank == 0 and not use_dist and args.in_flight > 1:
         # Pairs that share a GPU go into BATCHED contexts (bbme_create_batch: every kernel works on all pairs of the context
         # at once): the device dispatches the dependent kernels of many streams no faster than one per ~4 us chip-wide, so
         # one context per pair is dispatch-bound (69 launches per pair); `--seq-batch` pairs per context, in_flight / batch
         # contexts (streams) side by side so that one context's searches overlap the others' latency-bound sweeps.
-        per = max(1, min(args.seq_batch, args.in_flight))
-        n_ctx = max(1, args.in_flight // per)
-        frames = [(t1, t2)]
-        for k in range(1, n_ctx * per):
+        seq_frames = [(t1, t2)]
+        for k in range(1, args.in_flight):
             g1, g2, _ = bbme.synth_pair(w, h, 1000 + 30 + k, max_motion=24)
-            frames.append((torch.from_numpy(g1).cuda(), torch.from_numpy(g2).cuda()))
-        ctxs = [bbme.MFBatch(frames[i * per:(i + 1) * per], [search] * levels, [block] * levels, levels, device=local_rank,
-                             frames_on_device=True) for i in range(n_ctx)]
-        for c in ctxs:
-            c.set_speculation(False)              # with pairs in flight the chip is busy anyway
-            c.estimate_async()
-        for c in ctxs:
-            c.synchronize()
-        seq_steps = max(2, args.steps // 2)
-        t0 = time.perf_counter()
-        for _ in range(seq_steps):
+            seq_frames.append((torch.from_numpy(g1).cuda(), torch.from_numpy(g2).cuda()))
+
+        def sequence_leg(n_in_flight, per):
+            per = max(1, min(per, n_in_flight))
+            n_ctx = max(1, n_in_flight // per)
+            frames = list(seq_frames[:n_ctx * per])
+            while len(frames) < n_ctx * per:      # deeper than the synthesised set: the same pairs rolled by a few pixels (new content,
+                k = len(frames)                   # same statistics; synthesising a 4K pair takes seconds of CPU time)
+                a1, a2 = seq_frames[k % len(seq_frames)]
+                sh = (3 * (k // len(seq_frames)), 5 * (k // len(seq_frames)))
+                frames.append((torch.roll(a1, sh, (0, 1)).contiguous(), torch.roll(a2, sh, (0, 1)).contiguous()))
+            ctxs = [bbme.MFBatch(frames[i * per:(i + 1) * per], [search] * levels, [block] * levels, levels, device=local_rank,
+                                 frames_on_device=True) for i in range(n_ctx)]
             for c in ctxs:
+                c.set_speculation(False)              # with pairs in flight the chip is busy anyway
                 c.estimate_async()
-        for c in ctxs:
-            c.synchronize()
-        dt = time.perf_counter() - t0
-        same = bool(np.array_equal(ctxs[0].get_pair_flow(0), result_flow))
-        n_pairs = n_ctx * per
-        sequence = {"pairs_in_flight": n_pairs, "contexts": n_ctx, "pairs_per_context": per,
-                    "value": round(blocks[0] * n_pairs * seq_steps / dt / 1e6, 4),
-                    "unit": "Mblocks/s", "ms_per_pair": round(dt / (seq_steps * n_pairs) * 1e3, 4),
-                    "pairs": seq_steps * n_pairs, "first_pair_field_unchanged": same,
-                    "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}
-        for c in ctxs:
-            c.close()
-        del frames
+            for c in ctxs:
+                c.synchronize()
+            seq_steps = max(2, args.steps // 2)
+            t0 = time.perf_counter()
+            for _ in range(seq_steps):
+                for c in ctxs:
+                    c.estimate_async()
+            for c in ctxs:
+                c.synchronize()
+            dt = time.perf_counter() - t0
+            same = bool(np.array_equal(ctxs[0].get_pair_flow(0), result_flow))
+            n_pairs = n_ctx * per
+            out = {"pairs_in_flight": n_pairs, "contexts": n_ctx, "pairs_per_context": per,
+                   "value": round(blocks[0] * n_pairs * seq_steps / dt / 1e6, 4),
+                   "unit": "Mblocks/s", "ms_per_pair": round(dt / (seq_steps * n_pairs) * 1e3, 4),
+                   "pairs": seq_steps * n_pairs, "first_pair_field_unchanged": same,
+                   "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}
+            for c in ctxs:
+                c.close()
+            return out
+
+        sequence = sequence_leg(args.in_flight, args.seq_batch)
+        if args.in_flight_deep > args.in_flight:
+            # a longer sequence: more pairs per context on the same four streams (each launch carries more work)
+            sequence_deep = sequence_leg(args.in_flight_deep, max(1, args.in_flight_deep // 4))
+        del seq_frames
 
     # the boundary with host buffers (never `value`): frames in (pinned) host memory -> upload (2 x 8.3 MB at 4K), padding +
     # pyramid on the GPU, estimate, download of the dense field (66.8 MB) or of the compact 2x2-cell grid (4.2 MB)
@@ -586,6 +633,8 @@ def main():
                               "unit": "GB/s", "frac": round(reg_gbs / HBM_PEAK_GBS, 5)}
         if sequence is not None:
             out["sequence"] = sequence
+        if sequence_deep is not None:
+            out["sequence_deep"] = sequence_deep
         if host_boundary is not None:
             out["host_boundary"] = host_boundary
         out["epe_vs_middlebury_gt"] = epe_on_ground_truth(bbme, local_rank)

@@ -582,6 +582,46 @@ def test_batched_context_matches_the_oracle_pair_by_pair(bbme, oracle, w, h, sea
         assert np.array_equal(got[p], exp[p]), "pair %d (device frames)" % p
 
 
+def test_deep_batches_match_the_oracle(bbme, oracle):
+    """The largest batch a context takes (BBME_MAX_BATCH = 64 pairs behind every launch; bench.py's `sequence_deep` legs) and
+    two deep contexts side by side on their own streams: every pair's field must be the oracle's.  Twelve distinct pairs and
+    the same pairs rolled by a few pixels (new content for the GPU, one more oracle run each only for the ones checked)."""
+    w, h, levels = 296, 200, 3
+    ss, bs = [30] * levels, [16] * levels
+    base = [bbme.synth_pair(w, h, 5200 + i, max_motion=6 + i)[:2] for i in range(12)]
+    pairs = []
+    for k in range(64):
+        f1, f2 = base[k % 12]
+        sh = (3 * (k // 12), 5 * (k // 12))
+        pairs.append((np.ascontiguousarray(np.roll(f1, sh, (0, 1))), np.ascontiguousarray(np.roll(f2, sh, (0, 1)))))
+
+    def expect(k):
+        omf = oracle.OracleMF(pairs[k][0], pairs[k][1], ss, bs)
+        out = omf.calc_motion_block_matching()
+        omf.close()
+        return out
+    checked = list(range(12)) + [12, 25, 38, 51, 63]
+    exp = {k: expect(k) for k in checked}
+    mb = bbme.MFBatch(pairs, ss, bs, levels)
+    assert mb.batch == 64
+    got = mb.calcMotionBlockMatching()
+    for k in checked:
+        assert np.array_equal(got[k], exp[k]), "pair %d of 64" % k
+    mb.close()
+    with pytest.raises(bbme.BbmeError):
+        bbme.MFBatch(pairs + pairs[:1], ss, bs, levels)            # 65 pairs: more than BBME_MAX_BATCH
+    a, b = bbme.MFBatch(pairs[:32], ss, bs, levels), bbme.MFBatch(pairs[32:], ss, bs, levels)
+    for _ in range(3):
+        a.estimate_async()
+        b.estimate_async()
+    ga, gb = a.calcMotionBlockMatching(), b.calcMotionBlockMatching()
+    for k in checked:
+        g = ga[k] if k < 32 else gb[k - 32]
+        assert np.array_equal(g, exp[k]), "pair %d (two contexts of 32)" % k
+    a.close()
+    b.close()
+
+
 @pytest.mark.parametrize("cfg", ["cfg2_1080p", "cfg3_4k", "cfg4_4k_b8"])
 def test_full_size_properties(bbme, cfg):
     """BASELINE.json's full sizes, through properties that need no oracle run:
