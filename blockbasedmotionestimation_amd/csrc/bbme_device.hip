@@ -49,6 +49,7 @@ struct Level {
     int nrounds = 0;
     uint32_t *tasks2 = nullptr, *rounds2 = nullptr;   // the plan for two waves per macroblock (levels of few blocks)
     int nrounds2 = 0;
+    uint2 *lane_ranks = nullptr, *lane_ranks2 = nullptr;   // per plan: the ranks of every lane's candidates (FastSearchArgs::lane_ranks)
     bool split_pays = false;                          // the two-wave plan is at least 20 % shorter per wave
     int fast_pitch_dw = 0;
     size_t fast_lds_bytes = 0;
@@ -198,13 +199,19 @@ int launch_search_fast(bbme_ctx *c, int level, int mode, hipStream_t stream, siz
     a.width = L.width; a.height = L.height;
     a.range = L.range; a.spiral = L.spiral;
     a.rank_of = L.rank_of; a.rank_pitch = L.rank_pitch;
-    a.tasks = L.tasks; a.rounds = L.rounds; a.nrounds = L.nrounds;
+    a.tasks = L.tasks; a.rounds = L.rounds; a.nrounds = L.nrounds; a.lane_ranks = L.lane_ranks;
+    {
+        const uint32_t nch = (uint32_t)(L.fast_pitch_dw + 3) / 4;
+        a.stage_magic = (65536u + nch - 1) / nch;
+        a.stage_rpp = 64u / nch;
+    }
     if (int rc = set_prediction_source(c, level, mode, a)) return rc;
     a.out = L.small[0];
     a.cols = L.width / L.block;
     a.pitch_dw = L.fast_pitch_dw;
     const int nblocks = (L.width / L.block) * (L.height / L.block);
     a.nblocks = nblocks;
+    a.cols_magic = (uint64_t)nblocks * (uint64_t)a.cols < (1ull << 32) ? (uint32_t)(((1ull << 32) + (uint64_t)a.cols - 1) / (uint64_t)a.cols) : 0u;
     a.xcd_remap = c->xcd_remap;
     const int grid = c->xcd_remap ? ((nblocks + 7) / 8) * 8 : nblocks;
     const size_t lds = std::max(L.fast_lds_bytes, lds_floor);
@@ -214,7 +221,8 @@ int launch_search_fast(bbme_ctx *c, int level, int mode, hipStream_t stream, siz
     // a level with fewer macroblocks than the chip has SIMDs: one wave per block leaves most SIMDs idle and every busy one
     // with a single wave, so the launch lasts as long as one block does -- two waves share each block then
     if (mode == kSearchPlain && L.tasks2 && nblocks <= c->split_blocks && (L.split_pays || c->split_forced)) {
-        a.tasks = L.tasks2; a.rounds = L.rounds2; a.nrounds = L.nrounds2;
+        a.tasks = L.tasks2; a.rounds = L.rounds2; a.nrounds = L.nrounds2; a.lane_ranks = L.lane_ranks2;
+        a.stage_rpp = 128u / ((uint32_t)(L.fast_pitch_dw + 3) / 4);
         if (L.block == 16) hipLaunchKernelGGL((k_search_fast<16, 2>), dim3(grid, P), dim3(128), lds, stream, a);
         else if (L.block == 32) hipLaunchKernelGGL((k_search_fast<32, 2>), dim3(grid, P), dim3(128), lds, stream, a);
         else hipLaunchKernelGGL((k_search_fast<8, 2>), dim3(grid, P), dim3(128), lds, stream, a);
@@ -593,13 +601,48 @@ int bbme_create_batch(const bbme_params *params, int width, int height, int devi
             L.fast_pitch_dw = plan.pitch_dw;
             // the window (+ for B <= 16 a copy of the block, 16-byte aligned, for the rim rounds of the tight plan)
             L.fast_lds_bytes = (((size_t)(L.block + 2 * L.range) * plan.pitch_dw + 3) & ~(size_t)3) * 4 + (size_t)L.block * L.block;
+            // the device copy of a plan's round codes carries, for strip rounds, where the round's rank entries start in
+            // lane_ranks (<< 16, in rows of T entries); lane_ranks itself: per strip round and lane the S entries of 4 ranks
+            auto upload_plan = [&](const SearchPlan &p, int T, uint32_t **d_tasks, uint32_t **d_rounds, uint2 **d_ranks) -> int {
+                std::vector<uint32_t> codes(p.rounds);
+                std::vector<uint16_t> ranks;
+                uint32_t cum = 0;
+                for (size_t rd = 0; rd < p.rounds.size(); ++rd) {
+                    if ((p.rounds[rd] >> 8) != 0) continue;
+                    const uint32_t S = p.rounds[rd] & 0xffu;
+                    if (cum > 0xffffu) return bbme::fail(BBME_ERR_STATE, "search plan of level %d: too many strip rows", l);
+                    codes[rd] |= cum << 16;
+                    for (int t = 0; t < T; ++t) {
+                        const uint32_t task = p.tasks[rd * (size_t)T + t];
+                        for (uint32_t d = 0; d < S; ++d)
+                            for (int cc = 0; cc < 4; ++cc) {
+                                uint16_t r = 0xffffu;                     // idle lane / padding column: masked in the kernel
+                                if (task != 0xffffffffu) {
+                                    const int dxi = 4 * (int)(task & 0xffu) + cc, dyi = (int)((task >> 8) & 0xffu) + (int)d;
+                                    if (dyi > 2 * L.range)
+                                        return bbme::fail(BBME_ERR_STATE, "search plan of level %d: a strip leaves the candidate square", l);
+                                    if (dxi < sp.rank_pitch) r = sp.rank_of[(size_t)dyi * sp.rank_pitch + dxi];
+                                }
+                                ranks.push_back(r);
+                            }
+                    }
+                    cum += S;
+                }
+                if (ranks.empty()) ranks.assign(4, 0xffffu);
+                hipError_t e;
+                if ((e = hipMalloc(d_tasks, p.tasks.size() * 4)) != hipSuccess ||
+                    (e = hipMalloc(d_rounds, codes.size() * 4)) != hipSuccess ||
+                    (e = hipMalloc(d_ranks, ranks.size() * 2 + 64)) != hipSuccess ||
+                    (e = hipMemcpy(*d_tasks, p.tasks.data(), p.tasks.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+                    (e = hipMemcpy(*d_rounds, codes.data(), codes.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+                    (e = hipMemcpy(*d_ranks, ranks.data(), ranks.size() * 2, hipMemcpyHostToDevice)) != hipSuccess)
+                    return bbme::fail(BBME_ERR_HIP, "allocating search plan of level %d: %s", l, hipGetErrorString(e));
+                return BBME_OK;
+            };
             if ((err = hipMalloc(&L.rank_of, sp.rank_of.size() * 2 + 64)) != hipSuccess ||
-                (err = hipMalloc(&L.tasks, plan.tasks.size() * 4)) != hipSuccess ||
-                (err = hipMalloc(&L.rounds, plan.rounds.size() * 4)) != hipSuccess ||
-                (err = hipMemcpy(L.rank_of, sp.rank_of.data(), sp.rank_of.size() * 2, hipMemcpyHostToDevice)) != hipSuccess ||
-                (err = hipMemcpy(L.tasks, plan.tasks.data(), plan.tasks.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
-                (err = hipMemcpy(L.rounds, plan.rounds.data(), plan.rounds.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
+                (err = hipMemcpy(L.rank_of, sp.rank_of.data(), sp.rank_of.size() * 2, hipMemcpyHostToDevice)) != hipSuccess)
                 return cleanup_fail(bbme::fail(BBME_ERR_HIP, "allocating search plan of level %d: %s", l, hipGetErrorString(err)));
+            if (int rc = upload_plan(plan, 64, &L.tasks, &L.rounds, &L.lane_ranks)) return cleanup_fail(rc);
             // shorter strips, so that the 128 lanes of two waves have a full round of them
             SearchPlan plan2 = plan_search(L.range, L.block, 8, 128);
             L.nrounds2 = (int)plan2.rounds.size();
@@ -612,11 +655,7 @@ int bbme_create_batch(const bbme_params *params, int width, int height, int devi
             };
             L.split_pays = 5 * walk(plan2) <= 4 * walk(plan);
             if (plan2.pitch_dw != plan.pitch_dw) return cleanup_fail(bbme::fail(BBME_ERR_STATE, "search plans disagree on the window pitch"));
-            if ((err = hipMalloc(&L.tasks2, plan2.tasks.size() * 4)) != hipSuccess ||
-                (err = hipMalloc(&L.rounds2, plan2.rounds.size() * 4)) != hipSuccess ||
-                (err = hipMemcpy(L.tasks2, plan2.tasks.data(), plan2.tasks.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
-                (err = hipMemcpy(L.rounds2, plan2.rounds.data(), plan2.rounds.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
-                return cleanup_fail(bbme::fail(BBME_ERR_HIP, "allocating search plan of level %d: %s", l, hipGetErrorString(err)));
+            if (int rc = upload_plan(plan2, 128, &L.tasks2, &L.rounds2, &L.lane_ranks2)) return cleanup_fail(rc);
         }
     }
     // pitch = 33 (mod 64) words: consecutive blocks land 132 bytes (mod 256) apart
@@ -657,6 +696,7 @@ int bbme_destroy(bbme_ctx *c)
         (void)hipFree(L.fix_list); (void)hipFree(L.fix_count);
         (void)hipFree(L.big[0]); (void)hipFree(L.big[1]); (void)hipFree(L.spiral);
         (void)hipFree(L.rank_of); (void)hipFree(L.tasks); (void)hipFree(L.rounds); (void)hipFree(L.tasks2); (void)hipFree(L.rounds2);
+        (void)hipFree(L.lane_ranks); (void)hipFree(L.lane_ranks2);
     }
     (void)hipFree(c->flow);
     (void)hipFree(c->epe_scratch);

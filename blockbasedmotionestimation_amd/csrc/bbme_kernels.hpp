@@ -80,8 +80,9 @@ __device__ __forceinline__ bool search_prediction(const Args &a, int i, int j, u
 {
     m = 0;
     if (a.coarse) {
-        const int ci = (i / (2 * a.coarse_block)) * a.coarse_block;
-        const int cj = (j / (2 * a.coarse_block)) * a.coarse_block;
+        const int lg = 31 - __builtin_clz((unsigned)a.coarse_block);      // block sizes are powers of two (validate_params): no division
+        const int ci = (i >> (lg + 1)) << lg;                              // (i / (2 B_{l+1})) * B_{l+1}, i >= 0
+        const int cj = (j >> (lg + 1)) << lg;
         m = a.coarse[(size_t)(ci >> a.coarse_cell_shift) * a.coarse_cols + (cj >> a.coarse_cell_shift)];
     }
     if (a.mode == kSearchFixup && a.pred[bid] == m) return false;       // searched from this prediction already
@@ -227,8 +228,13 @@ struct FastSearchArgs {
     const uint16_t *rank_of;    // [(dy+R) * rank_pitch + (dx+R)] -> rank, 0xffff where dx > R
     int rank_pitch;             // multiple of 4
     const uint32_t *tasks;      // nrounds * 64 entries: g | dy0 << 8, 0xffffffff = idle lane
-    const uint32_t *rounds;     // nrounds entries: strip height S
+    const uint32_t *rounds;     // nrounds entries: strip height S | kind << 8 | (strip rounds) first row of the round in lane_ranks << 16
     int nrounds;
+    const uint2 *lane_ranks;    // strip rounds: the ranks of a lane's candidates, S entries of 4 x u16 (columns 4g..4g+3 of row dy0 + d),
+                                // contiguous per lane: entry ((code >> 16) * T + tid * S + d), T = 64 x waves per block
+    uint32_t cols_magic;        // ceil(2^32 / cols) when nblocks * cols < 2^32 (then bid / cols == mulhi(bid, magic)), else 0
+    uint32_t stage_magic;       // ceil(65536 / nch), nch = ceil(pitch_dw / 4): tid / nch == (tid * magic) >> 16 for tid < 256
+    uint32_t stage_rpp;         // T / nch: window rows one staging pass covers
     const mv_t *coarse;         // prediction source, as in SearchArgs
     int coarse_cols, coarse_block, coarse_cell_shift;
     int mode;
@@ -249,6 +255,24 @@ __device__ __forceinline__ void shift_pair(FastSearchArgs &a, uint32_t p)
     a.fix_count += (size_t)p * 16u;
 }
 
+// bid / cols without the (floating-point reciprocal) division sequence: one scalar multiply for a uniform bid
+__device__ __forceinline__ uint32_t block_row(const FastSearchArgs &a, uint32_t bid)
+{
+    return a.cols_magic ? __umulhi(bid, a.cols_magic) : bid / (uint32_t)a.cols;
+}
+
+// minimum over the wave, in every lane: four DPP steps inside the rows of 16 lanes, then the four row minima through scalar registers
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x)
+{
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, false));     // quad_perm [1,0,3,2]
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false));     // quad_perm [2,3,0,1]
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xf, 0xf, false));    // row_half_mirror
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xf, 0xf, false));    // row_mirror
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)x, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)x, 16);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)x, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)x, 48);
+    return min(min(r0, r1), min(r2, r3));
+}
+
 // Current block operand: B <= 16 keeps the whole block in SGPRs; B = 32 keeps its address, and search_strip brings the block
 // through the SGPRs eight rows at a time.
 template <int B> struct CurBlock {
@@ -261,7 +285,8 @@ template <int B> struct CurBlock {
 template <int B, int S>
 __device__ __forceinline__ uint32_t search_strip(const uint32_t *win, int P, const CurBlock<B> &cur,
                                                  uint32_t task, const FastSearchArgs &a, uint32_t best,
-                                                 bool border, int xlo, int xhi, int ylo, int yhi)
+                                                 bool border, int xlo, int xhi, int ylo, int yhi,
+                                                 const char *rk, uint32_t rk_off)
 {
     constexpr int BW = B / 4;
     // packed u16 sums hold at most 256 pixels (255 * 256 < 2^16): B = 32 flushes them into 32-bit sums after every 8 block rows
@@ -372,10 +397,8 @@ __device__ __forceinline__ uint32_t search_strip(const uint32_t *win, int P, con
         const int dxi = 4 * g + c;
         if (dxi > 2 * a.range || (border && (dxi < xlo || dxi > xhi))) colmask |= 0xffffull << (16 * c);
     }
-    // rank rows: uniform base (advanced in scalar registers) + one 32-bit byte offset per lane
-    const char *rk = reinterpret_cast<const char *>(a.rank_of);
-    const uint32_t rk_off = ((uint32_t)dy0 * (uint32_t)a.rank_pitch + 4u * (uint32_t)g) * 2u;
-    const uint32_t rk_step = (uint32_t)a.rank_pitch * 2u;
+    // the ranks of this lane's 4 S candidates: S entries of 8 bytes, contiguous (FastSearchArgs::lane_ranks) -- `rk` is the
+    // round's uniform base, rk_off the lane's byte offset, the entries follow at constant offsets
     if constexpr (!WIDE) {
         // away from the image border, in a round without idle lanes or padding columns (every strip round of the tight plan),
         // no candidate needs masking: four v_perm and the minimum per candidate row, nothing else
@@ -385,7 +408,7 @@ __device__ __forceinline__ uint32_t search_strip(const uint32_t *win, int P, con
             for (int d0 = 0; d0 < S; d0 += CH) {
                 uint2 r4[CH];
 #pragma unroll
-                for (int d = 0; d < CH; ++d) { r4[d] = *reinterpret_cast<const uint2 *>(rk + rk_off); rk += rk_step; }
+                for (int d = 0; d < CH; ++d) r4[d] = *reinterpret_cast<const uint2 *>(rk + rk_off + 8 * (d0 + d));
 #pragma unroll
                 for (int d = 0; d < CH; ++d) {
                     const uint32_t lo = (uint32_t)acc[d0 + d], hi = (uint32_t)(acc[d0 + d] >> 32);
@@ -393,7 +416,8 @@ __device__ __forceinline__ uint32_t search_strip(const uint32_t *win, int P, con
                     const uint32_t k1 = __builtin_amdgcn_perm(lo, r4[d].x, 0x07060302u);
                     const uint32_t k2 = __builtin_amdgcn_perm(hi, r4[d].y, 0x05040100u);
                     const uint32_t k3 = __builtin_amdgcn_perm(hi, r4[d].y, 0x07060302u);
-                    best = min(best, min(min(k0, k1), min(k2, k3)));
+                    best = min(min(best, k0), k1);                 // two v_min3_u32
+                    best = min(min(best, k2), k3);
                 }
                 asm volatile("" ::: "memory");
             }
@@ -402,8 +426,7 @@ __device__ __forceinline__ uint32_t search_strip(const uint32_t *win, int P, con
     }
 #pragma unroll
     for (int d = 0; d < S; ++d) {
-        const uint2 r4 = *reinterpret_cast<const uint2 *>(rk + rk_off);
-        rk += rk_step;
+        const uint2 r4 = *reinterpret_cast<const uint2 *>(rk + rk_off + 8 * d);
         const bool row_bad = border && (dy0 + d < ylo || dy0 + d > yhi);
         if constexpr (!WIDE) {
             unsigned long long v = acc[d] | colmask;
@@ -463,6 +486,7 @@ __device__ __forceinline__ uint32_t search_row_parts(const uint32_t *win, const 
     if (idle || part != 0) return best;
     const uint2 r4 = *reinterpret_cast<const uint2 *>(a.rank_of + (size_t)dyi * a.rank_pitch + 4 * g);
     if (border) {
+        asm volatile("" ::: "memory");                          // a real branch: the interior path must not pay for the masking
         if (dyi < ylo || dyi > yhi) return best;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -517,10 +541,12 @@ __device__ __forceinline__ void search_block_fast(const FastSearchArgs &a, uint3
     constexpr int T = 64 * W;                                // threads staging the window
     const int lane = threadIdx.x & 63;
     const int tid = W == 1 ? lane : (int)threadIdx.x;
-    const int bc = (int)(bid % (uint32_t)a.cols), br = (int)(bid / (uint32_t)a.cols);
+    const int br = (int)block_row(a, bid), bc = (int)bid - br * a.cols;
     const int i = br * B, j = bc * B;
     const int u = 2 * mv_x(m), v = 2 * mv_y(m);             // copyMVs doubles the coarse MV (:836)
-    const int px = j + u, py = i + v;                       // :233-234
+    // :233-234; the whole workgroup searches one block from one prediction: said so, the window geometry, the border tests
+    // and the staging base address below stay in scalar registers
+    const int px = __builtin_amdgcn_readfirstlane(j + u), py = __builtin_amdgcn_readfirstlane(i + v);
     mv_t *dst = a.out + (size_t)br * a.cols + bc;
     if (px < 0 || py < 0 || px + B > a.width || py + B > a.height) {    // :304-310 (workgroup-uniform)
         if (tid == 0) *dst = 0;
@@ -537,19 +563,21 @@ __device__ __forceinline__ void search_block_fast(const FastSearchArgs &a, uint3
     const int wbytes = 4 * P;
     if (wx0 >= 0 && wx0 + wbytes <= a.width && wy0 >= 0 && wy0 + wrows <= a.height) {
         const int nch = (P + 3) >> 2;                        // chunks per row, the last one partial
-        const int rpp = T / nch;                             // rows per pass
-        const int rr = tid / nch, ch = tid - rr * nch;
+        const int rpp = (int)a.stage_rpp;                    // rows per pass: T / nch
+        const int rr = (int)(((uint32_t)tid * a.stage_magic) >> 16), ch = tid - rr * nch;      // tid / nch, tid % nch
         const int nd = min(4, P - 4 * ch);                   // dwords of this lane's chunk that belong to the row
-        const uint8_t *src = a.image2 + (size_t)(wy0 + rr) * a.width + wx0 + 16 * ch;
+        // uniform base (scalar registers, advanced there from pass to pass) + one 32-bit byte offset per lane
+        const uint8_t *ubase = a.image2 + ((size_t)wy0 * (size_t)a.width + (size_t)wx0);
+        const uint32_t loff = (uint32_t)rr * (uint32_t)a.width + 16u * (uint32_t)ch;
         uint32_t *dstw = smem + rr * P + 4 * ch;
-        const size_t sstep = (size_t)rpp * a.width;
+        const uint32_t sstep = (uint32_t)rpp * (uint32_t)a.width;
         const int dstep = rpp * P;
         constexpr int U = 8;
         for (int row0 = rr; row0 < wrows; row0 += rpp * U) {
             ua_u128 v[U];
 #pragma unroll
             for (int t = 0; t < U; ++t)
-                if (rr < rpp && row0 + t * rpp < wrows) v[t] = *reinterpret_cast<const ua_u128 *>(src + t * sstep);
+                if (rr < rpp && row0 + t * rpp < wrows) v[t] = *reinterpret_cast<const ua_u128 *>(ubase + (size_t)((uint32_t)t * sstep) + loff);
 #pragma unroll
             for (int t = 0; t < U; ++t)
                 if (rr < rpp && row0 + t * rpp < wrows) {
@@ -557,7 +585,7 @@ __device__ __forceinline__ void search_block_fast(const FastSearchArgs &a, uint3
                     for (int q = 0; q < 4; ++q)
                         if (q < nd) dstw[t * dstep + q] = v[t].v[q];
                 }
-            src += U * sstep;
+            ubase += (size_t)U * sstep;
             dstw += U * dstep;
         }
     } else {
@@ -617,23 +645,26 @@ __device__ __forceinline__ void search_block_fast(const FastSearchArgs &a, uint3
         const uint32_t code = a.rounds[rd];                 // strip height S | kind << 8 (plan_search)
         const uint32_t S = code & 0xffu;
         const uint32_t task = a.tasks[rd * T + tid];
-        if (code >> 8) {
+        const uint32_t kind = (code >> 8) & 0xffu;
+        if (kind) {
             if constexpr (B <= 16) {
-                if ((code >> 8) == 1u) best = search_row_parts<B>(smem, cur_lds, P, task, a, best, border, xlo, xhi, ylo, yhi);
+                if (kind == 1u) best = search_row_parts<B>(smem, cur_lds, P, task, a, best, border, xlo, xhi, ylo, yhi);
                 else best = search_aligned_column<B>(smem, P, cur, task, a, best, border, xlo, xhi, ylo, yhi);
             }
             continue;
         }
+        // the round's rank entries: uniform base + this lane's S entries of 8 bytes
+        const char *rk = reinterpret_cast<const char *>(a.lane_ranks) + (size_t)((code >> 16) * (uint32_t)T) * 8u;
+        const uint32_t rk_off = (uint32_t)tid * S * 8u;
         switch (S) {
-        case 16: if constexpr (B <= 16) { best = search_strip<B, 16>(smem, P, cur, task, a, best, border, xlo, xhi, ylo, yhi); } break;
-        case 8:  best = search_strip<B, 8>(smem, P, cur, task, a, best, border, xlo, xhi, ylo, yhi); break;
-        case 4:  best = search_strip<B, 4>(smem, P, cur, task, a, best, border, xlo, xhi, ylo, yhi); break;
-        case 2:  best = search_strip<B, 2>(smem, P, cur, task, a, best, border, xlo, xhi, ylo, yhi); break;
-        default: best = search_strip<B, 1>(smem, P, cur, task, a, best, border, xlo, xhi, ylo, yhi); break;
+        case 16: if constexpr (B <= 16) { best = search_strip<B, 16>(smem, P, cur, task, a, best, border, xlo, xhi, ylo, yhi, rk, rk_off); } break;
+        case 8:  best = search_strip<B, 8>(smem, P, cur, task, a, best, border, xlo, xhi, ylo, yhi, rk, rk_off); break;
+        case 4:  best = search_strip<B, 4>(smem, P, cur, task, a, best, border, xlo, xhi, ylo, yhi, rk, rk_off); break;
+        case 2:  best = search_strip<B, 2>(smem, P, cur, task, a, best, border, xlo, xhi, ylo, yhi, rk, rk_off); break;
+        default: best = search_strip<B, 1>(smem, P, cur, task, a, best, border, xlo, xhi, ylo, yhi, rk, rk_off); break;
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o));
+    best = wave_min_u32(best);
     if constexpr (W > 1) {
         __shared__ uint32_t wave_best[W];
         if (lane == 0) wave_best[threadIdx.x >> 6] = best;
@@ -660,7 +691,8 @@ __global__ __launch_bounds__(64 * W, (W == 1 && B <= 16 ? 5 : 1)) void k_search_
     if (a.mode == kSearchSpeculative && blockIdx.x == 0 && threadIdx.x == 0) *a.fix_count = 0;   // for the fix-up behind this launch
     if (bid >= (uint32_t)a.nblocks) return;
     mv_t m;                                                 // copyMVs (:828-843)
-    if (!search_prediction(a, (int)(bid / (uint32_t)a.cols) * B, (int)(bid % (uint32_t)a.cols) * B, bid, m)) return;
+    const uint32_t brow = block_row(a, bid);
+    if (!search_prediction(a, (int)brow * B, (int)(bid - brow * (uint32_t)a.cols) * B, bid, m)) return;
     search_block_fast<B, W>(a, bid, m, smem);
 }
 
@@ -702,9 +734,10 @@ __global__ __launch_bounds__(64, (B <= 16 ? 5 : 1)) void k_search_list(FastSearc
     list += (size_t)blockIdx.y * a.s_fix_list;
     const uint32_t n = *a.fix_count;
     for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {               // wave-uniform
-        const uint32_t bid = list[e];
+        const uint32_t bid = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[e]);
+        const uint32_t brow = block_row(a, bid);
         mv_t m;
-        (void)search_prediction(a, (int)(bid / (uint32_t)a.cols) * B, (int)(bid % (uint32_t)a.cols) * B, bid, m);   // a.mode == kSearchPlain
+        (void)search_prediction(a, (int)brow * B, (int)(bid - brow * (uint32_t)a.cols) * B, bid, m);   // a.mode == kSearchPlain
         search_block_fast<B>(a, bid, m, smem);
         __syncthreads();                                                   // the window in LDS is re-used
     }
