@@ -38,20 +38,53 @@ WORKLOADS = {
     "cfg1": (584, 388, 30, 16, 3, "cfg1: RubberWhale-sized synthetic pair, 16x16 blocks, +-7, 3 levels"),
     "ref": (2336, 1552, 64, 32, 4, "reference literals (main_class.cpp:19-21): 584x388 frame up-sampled x4, 32x32 blocks, "
                                    "search 64 (+-16), 4 levels"),
+    # the author's OTHER literal set, commented out at main_class.cpp:15-17 (index 0 = finest level): mixed block sizes, and an
+    # odd shift at the coarsest level (42 - 32 = 10 -> R = 5) with 32 x 32 blocks over 16 x 16 ones
+    "ref2": (584, 388, [32, 32, 42], [16, 16, 32], 3, "reference's second literal set (main_class.cpp:15-17): 584x388 frame, block "
+                                                       "{16,16,32}, search {32,32,42} (+-8, +-8, +-5), 3 levels"),
 }
+HEADLINE_WORKLOADS = sorted(k for k, v in WORKLOADS.items() if not isinstance(v[2], list))   # --workload: one block size / range
 # pairs in flight of the `sequence_deep` legs (4 batched contexts): small frames are launch-bound, so they take deeper batches
-DEEP_SEQUENCE = {"cfg1": 64, "cfg2": 32, "cfg4": 24, "ref": 32}
+DEEP_SEQUENCE = {"cfg1": 64, "cfg2": 32, "cfg4": 24, "ref": 32, "ref2": 64}
+
+
+def per_level(v, levels):
+    """search_size[] / block_size[] of a workload (index 0 = finest level) from one value or a list"""
+    return list(v)[:levels] if isinstance(v, (list, tuple)) else [v] * levels
 
 
 def level_blocks(pw, ph, block, levels):
-    return [((pw >> l) // block) * ((ph >> l) // block) for l in range(levels)]
+    return [((pw >> l) // b) * ((ph >> l) // b) for l, b in enumerate(per_level(block, levels))]
+
+
+def check_all_pairs(bbme, ctxs, frames, per, search, block, levels, device):
+    """Every pair of every batched context against a context of its own on the same frames (the int16 2x2-cell grids: exactly
+    the information of the dense field).  Outside every timed region."""
+    mf, ok = None, True
+    if os.environ.get("BBME_BENCH_NO_PAIRCHECK"):
+        return None
+    for i, (a1, a2) in enumerate(frames):
+        if mf is None:
+            mf = bbme.MF(a1, a2, per_level(search, levels), per_level(block, levels), levels, device=device, frames_on_device=True)
+            # no second (lowest-priority) stream: a context that speculates leaves the following legs' streams on slower hardware
+            # queues (measured: the sequence legs behind a speculating checker lose 10-65 %)
+            mf.set_speculation(False)
+        else:
+            mf.set_frames_device(a1, a2)
+        mf.estimate_async()
+        mf.synchronize()
+        ok = ok and bool(np.array_equal(mf.get_cells(), ctxs[i // per].get_pair_cells(i % per)))
+    if mf is not None:
+        mf.close()
+    return ok
 
 
 def pmc_traffic(levels):
-    """Mean HBM-side bytes per search launch from the committed rocprofv3 --pmc passes
+    """(mean HBM-side bytes per search launch, where the figure comes from) from the committed rocprofv3 --pmc passes
     (profiles/rNN_pmc_search.json, made by scripts/pmc_report.py: FETCH_SIZE scaled by the factor
-    measured on a calibration read of known size in the same run, plus WRITE_SIZE).  Only quoted
-    when a file was measured on exactly this kernel source; otherwise None."""
+    measured on a calibration read of known size in the same run, plus WRITE_SIZE).  It is a QUOTE of a committed
+    measurement, not a measurement of this run: only given when the file was measured on exactly this kernel
+    source (sha256 of bbme_kernels.hpp); otherwise (None, None)."""
     import glob
     import hashlib
     src = os.path.join(ROOT, "blockbasedmotionestimation_amd", "csrc", "bbme_kernels.hpp")
@@ -63,10 +96,12 @@ def pmc_traffic(levels):
                 continue
             vals = [v["hbm_bytes"] for k, v in d["kernels"].items() if k.startswith("k_search")]
             if len(vals) == levels:
-                return sum(vals) / len(vals)
+                return sum(vals) / len(vals), {"file": os.path.relpath(path, ROOT), "kernel_source_sha256": digest[:16],
+                                               "kind": "quoted from a committed rocprofv3 --pmc pass on this kernel source, "
+                                                       "not measured in this run"}
         except (OSError, ValueError, KeyError):
             pass
-    return None
+    return None, None
 
 
 def pmc_sq_summary():
@@ -172,7 +207,7 @@ def oracle_flow(f1, f2, search, block, levels, threads):
     (the regulariser sweeps stay sequential: they are order dependent)."""
     O = native_oracle(threads > 1)
     os.environ["OMP_NUM_THREADS"] = str(threads)
-    omf = O.OracleMF(f1, f2, [search] * levels, [block] * levels, use_cache=False)
+    omf = O.OracleMF(f1, f2, per_level(search, levels), per_level(block, levels), use_cache=False)
     t0 = time.perf_counter()
     flow = omf.calc_motion_block_matching()
     dt = time.perf_counter() - t0
@@ -202,7 +237,7 @@ def other_workload(bbme, torch, name, device, steps, warmup, check):
     the CPU oracle's on the same pair (all host cores), None when the CPU legs are switched off."""
     w, h, search, block, levels, desc = WORKLOADS[name]
     f1, f2, _ = bbme.synth_pair(w, h, 1000 + 30, max_motion=24)
-    mf = bbme.MF(torch.from_numpy(f1).cuda(), torch.from_numpy(f2).cuda(), [search] * levels, [block] * levels, levels,
+    mf = bbme.MF(torch.from_numpy(f1).cuda(), torch.from_numpy(f2).cuda(), per_level(search, levels), per_level(block, levels), levels,
                  device=device, frames_on_device=True)
     mf.synchronize()
     for _ in range(warmup):
@@ -234,7 +269,7 @@ def other_workload(bbme, torch, name, device, steps, warmup, check):
     for k in range(1, 8):
         g1, g2, _ = bbme.synth_pair(w, h, 1000 + 30 + k, max_motion=24)
         frames.append((torch.from_numpy(g1).cuda(), torch.from_numpy(g2).cuda()))
-    ctxs = [bbme.MFBatch(frames[2 * i:2 * i + 2], [search] * levels, [block] * levels, levels, device=device, frames_on_device=True)
+    ctxs = [bbme.MFBatch(frames[2 * i:2 * i + 2], per_level(search, levels), per_level(block, levels), levels, device=device, frames_on_device=True)
             for i in range(4)]
     for c in ctxs:
         c.set_speculation(False)
@@ -249,10 +284,12 @@ def other_workload(bbme, torch, name, device, steps, warmup, check):
         c.synchronize()
     dts = (time.perf_counter() - t0) / (steps * 8)
     same = bool(np.array_equal(ctxs[0].get_pair_flow(0), flow))
+    all_ok = check_all_pairs(bbme, ctxs, frames[:8], 2, search, block, levels, device)
     for c in ctxs:
         c.close()
     out["sequence_8_pairs"] = {"value": round(blocks[0] / dts / 1e6, 4), "unit": "Mblocks/s", "ms_per_pair": round(dts * 1e3, 4),
-                               "contexts": 4, "pairs_per_context": 2, "first_pair_field_unchanged": same}
+                               "contexts": 4, "pairs_per_context": 2, "first_pair_field_unchanged": same,
+                               "all_pairs_checked": all_ok}
     # a longer sequence on the same four streams: more pairs per batched context (the same eight pairs rolled by a few pixels)
     deep = DEEP_SEQUENCE.get(name, 0)
     if deep > 8:
@@ -261,7 +298,7 @@ def other_workload(bbme, torch, name, device, steps, warmup, check):
             k = len(frames)
             sh = (3 * (k // 8), 5 * (k // 8))
             frames.append((torch.roll(frames[k % 8][0], sh, (0, 1)).contiguous(), torch.roll(frames[k % 8][1], sh, (0, 1)).contiguous()))
-        ctxs = [bbme.MFBatch(frames[per * i:per * (i + 1)], [search] * levels, [block] * levels, levels, device=device,
+        ctxs = [bbme.MFBatch(frames[per * i:per * (i + 1)], per_level(search, levels), per_level(block, levels), levels, device=device,
                              frames_on_device=True) for i in range(4)]
         for c in ctxs:
             c.set_speculation(False)
@@ -276,11 +313,12 @@ def other_workload(bbme, torch, name, device, steps, warmup, check):
             c.synchronize()
         dts = (time.perf_counter() - t0) / (steps * deep)
         same = bool(np.array_equal(ctxs[0].get_pair_flow(0), flow))
+        all_ok = check_all_pairs(bbme, ctxs, frames[:4 * per], per, search, block, levels, device)
         for c in ctxs:
             c.close()
         out["sequence_deep"] = {"pairs_in_flight": deep, "value": round(blocks[0] / dts / 1e6, 4), "unit": "Mblocks/s",
                                 "ms_per_pair": round(dts * 1e3, 4), "contexts": 4, "pairs_per_context": per,
-                                "first_pair_field_unchanged": same,
+                                "first_pair_field_unchanged": same, "all_pairs_checked": all_ok,
                                 "note": "pairs beyond the 8 synthesised ones are the same pairs rolled by a few pixels"}
     return out
 
@@ -290,10 +328,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cfg3", choices=HEADLINE_WORKLOADS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-iters", type=int, default=5)
-    ap.add_argument("--no-other-workloads", action="store_true", help="skip the `other_workloads` legs (cfg2, cfg4, cfg1, ref)")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the `other_workloads` legs (cfg2, cfg4, cfg1, ref, ref2)")
     ap.add_argument("--no-host-boundary", action="store_true",
                     help="skip the host_boundary legs (for kernel traces: their pyramids start from freshly uploaded frames)")
     ap.add_argument("--in-flight", type=int, default=8,
@@ -334,7 +372,7 @@ def main():
     f1, f2, _ = bbme.synth_pair(w, h, 1000 + 30 + rank, max_motion=24)      # one pair per GPU (weak scaling)
     t1 = torch.from_numpy(f1).cuda()
     t2 = torch.from_numpy(f2).cuda()
-    mf = bbme.MF(t1, t2, [search] * levels, [block] * levels, levels, device=local_rank, frames_on_device=True)
+    mf = bbme.MF(t1, t2, per_level(search, levels), per_level(block, levels), levels, device=local_rank, frames_on_device=True)
     mf.synchronize()
     pw, ph = mf.padded_width, mf.padded_height
     blocks = level_blocks(pw, ph, block, levels)
@@ -427,7 +465,7 @@ def main():
                 a1, a2 = seq_frames[k % len(seq_frames)]
                 sh = (3 * (k // len(seq_frames)), 5 * (k // len(seq_frames)))
                 frames.append((torch.roll(a1, sh, (0, 1)).contiguous(), torch.roll(a2, sh, (0, 1)).contiguous()))
-            ctxs = [bbme.MFBatch(frames[i * per:(i + 1) * per], [search] * levels, [block] * levels, levels, device=local_rank,
+            ctxs = [bbme.MFBatch(frames[i * per:(i + 1) * per], per_level(search, levels), per_level(block, levels), levels, device=local_rank,
                                  frames_on_device=True) for i in range(n_ctx)]
             for c in ctxs:
                 c.set_speculation(False)              # with pairs in flight the chip is busy anyway
@@ -443,11 +481,12 @@ def main():
                 c.synchronize()
             dt = time.perf_counter() - t0
             same = bool(np.array_equal(ctxs[0].get_pair_flow(0), result_flow))
+            all_ok = check_all_pairs(bbme, ctxs, frames, per, search, block, levels, local_rank)
             n_pairs = n_ctx * per
             out = {"pairs_in_flight": n_pairs, "contexts": n_ctx, "pairs_per_context": per,
                    "value": round(blocks[0] * n_pairs * seq_steps / dt / 1e6, 4),
                    "unit": "Mblocks/s", "ms_per_pair": round(dt / (seq_steps * n_pairs) * 1e3, 4),
-                   "pairs": seq_steps * n_pairs, "first_pair_field_unchanged": same,
+                   "pairs": seq_steps * n_pairs, "first_pair_field_unchanged": same, "all_pairs_checked": all_ok,
                    "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}
             for c in ctxs:
                 c.close()
@@ -568,7 +607,7 @@ def main():
         loops = (C.c_double * 2)()
         _capi.check(_capi.lib().bbme_probe_search_loops(local_rank, loops))
         value = units * args.steps / elapsed / 1e6
-        # dominant kernel: k_search_generic<B>, one launch per level.  Algorithmic bytes per block
+        # dominant kernel (by arithmetic): k_search_fast<B, W>, one launch per level.  Algorithmic bytes per block
         # = B^2 + (B+2R)^2 + 8; "per launch" = mean over the `levels` launches of a pyramid.
         bytes_per_block = block * block + (block + 2 * R) ** 2 + 8
         search_bytes = sum(blocks) * bytes_per_block / levels
@@ -579,6 +618,10 @@ def main():
         seen, viol = C.c_int(), C.c_int()
         _capi.check(_capi.lib().bbme_probe_xcd(local_rank, C.byref(seen), C.byref(viol)))
         xcd_check = {"xcds_seen": seen.value, "workgroups_off_their_residue_class": viol.value, "of": 4096}
+        traffic, traffic_source = pmc_traffic(levels)
+        ms_step = elapsed / args.steps * 1e3
+        step_absdiff = sum(blocks) * (2 * R + 1) ** 2 * block * block * world      # the searches of one step, all levels
+        step_tabs = step_absdiff / (ms_step * 1e-3) / 1e12
         out = {
             "metric": "Mblocks/s (16x16, +-32 full search)", "value": round(value, 4), "unit": "Mblocks/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -597,12 +640,16 @@ def main():
             "roofline": {"bound": "valu", "kernel": "k_search_fast<%d, W> (mean of the %d per-level launches; W = 2 waves per macroblock on levels of "
                                    "<= 10000 blocks, else 1)" % (block, levels),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(levels),
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": round(search_bytes),
                          "avg_launch_ms": round(search_ms, 5),
                          "binding": {"unit": "T abs-diff/s", "achieved": round(tabs, 3), "peak": VALU_SAD_PEAK_T,
                                      "frac": round(tabs / VALU_SAD_PEAK_T, 5),
-                                     "peak_source": "spec: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz x 4 abs-diff per v_sad_u8 lane-op",
+                                     "peak_source": "256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz x 4 abs-diff per v_sad_u8 lane-op: the "
+                                                    "ceiling of the SAD INSTRUCTIONS, not of the VALU -- v_sad_u8 holds its SIMD for 4 cycles "
+                                                    "per wave64 instruction (v_qsad_pk_u16_u8 for 16) although the SIMD retires v_fma_f32 "
+                                                    "at 32 lanes/clk; the v_sad_u8 probe below (137-140 T/s at the 2.1-2.2 GHz the chip "
+                                                    "holds under this load) is that 4-cycle reading measured",
                                      "measured_ceilings_Tabsdiff_s": {
                                          "v_qsad_pk_u16_u8 issue rate, VGPR operands": round(qsad_peak, 2),
                                          "v_sad_u8 issue rate": round(sad_peak, 2),
@@ -617,6 +664,12 @@ def main():
                             "blocks": sum(blocks), "ms": round(prof["search_ms"], 4),
                             "note": "the %d search launches alone (all-level block count), from the eager HIP-event pass" % levels},
             "device_ms": {k: round(val, 4) for k, val in prof.items()},
+            # the WHOLE step against the roofline that binds its arithmetic (what main_class.cpp:47-55 times): the searches'
+            # abs-diffs of all levels over ms_per_step.  The regulariser adds < 2 % arithmetic and most of the time (latency).
+            "step_binding": {"unit": "T abs-diff/s", "absdiffs_per_step": step_absdiff, "ms_per_step": round(ms_step, 4),
+                             "achieved": round(step_tabs, 3), "peak": VALU_SAD_PEAK_T, "frac": round(step_tabs / VALU_SAD_PEAK_T, 5),
+                             "note": "search abs-diffs of every level / the timed step (search + regulariser + expand); "
+                                     "roofline.binding prices the search launches alone"},
         }
         # the regulariser takes most of the step although it is 2 % of the arithmetic: every sweep is a
         # chain of dependent block updates.  Algorithmic bytes of a sweep at block size b: per b x b block
@@ -665,7 +718,7 @@ def main():
             # the other single-GPU BASELINE configs (never `value`): the driver's one command times them all
             out["other_workloads"] = {name: other_workload(bbme, torch, name, local_rank, max(4, args.steps // 4), 3,
                                                            not args.no_cpu_baseline)
-                                      for name in ("cfg2", "cfg4", "cfg1", "ref") if name != args.workload}
+                                      for name in ("cfg2", "cfg4", "cfg1", "ref", "ref2") if name != args.workload}
         if not args.no_cpu_baseline:
             (dt1, _, par1), (dtn, threads, parn) = cpu_baseline(f1, f2, search, block, levels, result_flow)
             model, nproc, usable, quota_text = cpu_info()

@@ -86,9 +86,19 @@ struct bbme_ctx {
     uint32_t *own = nullptr;                      // ownership counters of the solver, one word per block
     uint32_t own_pitch = 0;                       // transposed layout: 32 residue classes of own_pitch words
     uint32_t *counters = nullptr;                 // 64 words (RegArgs::counters)
+    // SAD memo of the regulariser's chain form (bbme_kernels.hpp, "SAD memo"): nine (MV, SAD) words per block at b >= 8
+    unsigned long long *memo = nullptr;
+    uint32_t memo_stride = 0;                     // words from pair to pair
+    size_t memo_blocks = 0;                       // blocks per pair it has room for
+    int memo_level = -1, memo_block = 0;          // the (level, block size) its slots describe; block 0 = nothing
+    bool use_memo = true;                         // BBME_MEMO
+    int memo_min_block = 16;                      // sweeps at smaller blocks run without it (8: measured slower); BBME_MEMO_MIN_B
+    bool memo_forward = false;                    // BBME_MEMO_FORWARD (measured slower: off)
     uint64_t frames_mask = 0;                     // bit p: pair p has frames (bbme_estimate needs every pair's)
     bool frames_set() const { return frames_mask == (batch >= 64 ? ~0ull : (1ull << batch) - 1ull); }
     double *epe_scratch = nullptr;                // partial sums + counts of bbme_calculate_mse_device (allocated on first use)
+    int local_rounds = 8;                         // k_reg_iter: heavy rounds of a tile per launch; BBME_LOCAL_ROUNDS
+    int wide_threshold = 16;                      // solver: queue length above which a round takes the throughput form; BBME_WIDE_THRESHOLD
     int solve_waves = 4;                          // waves per solver workgroup (1, 2 or 4); BBME_SOLVE_WAVES
     int solve_wgs = 128;                          // most workgroups of k_reg_solve (4 independent waves each): one wave per SIMD
     int xcd_remap = 1;                            // XCD-aware block order in k_search_fast; BBME_XCD_REMAP
@@ -298,6 +308,12 @@ void launch_sweep_t(RegArgs a, uint8_t *const flags[2], int relax_steps, int max
     // grids up to ~130 000 blocks: the chain form of pass 1 (a third of the instructions per wave; 16 lanes per block fill the
     // chip from ~32 000 blocks on, and it still wins up to four times that: 1.815 -> 1.78 ms per cfg3 pair; slower from 500 000)
     auto pass1 = [&]() {
+        if constexpr (BS >= 8) {
+            if (a.memo) {                                  // (launch_sweep hands a memo only to sweeps whose pass 1 has the chain form)
+                hipLaunchKernelGGL((k_reg_pass1_lanes<BS, true>), dim3((unsigned)((blocks * 16 + 255) / 256), P), dim3(256), 0, s, a);
+                return;
+            }
+        }
         if (BS <= 16 && blocks <= lanes_max)               // (b >= 32: a lane would walk 32+ rows -- 13 against 6 us at b = 32)
             hipLaunchKernelGGL(k_reg_pass1_lanes<BS>, dim3((unsigned)((blocks * 16 + 255) / 256), P), dim3(256), 0, s, a);
         else
@@ -320,11 +336,19 @@ void launch_sweep_t(RegArgs a, uint8_t *const flags[2], int relax_steps, int max
     }
     a.flag_cur = flags[cur]; a.flag_next = nullptr;
     // small grids: scan segments of 4 flags, so that the stale blocks of a row are dealt to four times as many waves
+    a.memo_init = 0;                                       // pass 1 has written every slot
+    if constexpr (BS >= 8) {
+        if (a.memo) {
+            if (blocks <= fine_max) hipLaunchKernelGGL((k_reg_solve<BS, 4, true>), dim3(grid2, P), dim3(64 * solve_waves), 0, s, a);
+            else hipLaunchKernelGGL((k_reg_solve<BS, 16, true>), dim3(grid2, P), dim3(64 * solve_waves), 0, s, a);
+            return;
+        }
+    }
     if (blocks <= fine_max) hipLaunchKernelGGL((k_reg_solve<BS, 4>), dim3(grid2, P), dim3(64 * solve_waves), 0, s, a);
     else hipLaunchKernelGGL((k_reg_solve<BS, 16>), dim3(grid2, P), dim3(64 * solve_waves), 0, s, a);
 }
 
-int launch_sweep(bbme_ctx *c, int level, int b, int mult)
+int launch_sweep(bbme_ctx *c, int level, int b, int mult, bool stats = false)
 {
     Level &L = c->lv[level];
     if (mult < 1) return bbme::fail(BBME_ERR_INVALID, "lambda multiplier %d", mult);
@@ -353,15 +377,25 @@ int launch_sweep(bbme_ctx *c, int level, int b, int mult)
     a.own_pitch = c->own_pitch;
     a.s_plane = L.plane_stride; a.s_old = L.grid_stride(a.old_grid); a.s_est = L.grid_stride(a.est);
     a.s_list = c->list_stride; a.s_own = c->own_stride; a.s_flag = (uint32_t)c->flag_bytes;
-    static const int rounds_env = getenv("BBME_LOCAL_ROUNDS") ? atoi(getenv("BBME_LOCAL_ROUNDS")) : 8;
-    a.local_rounds = std::max(1, rounds_env);
-    static const int wide_env = getenv("BBME_WIDE_THRESHOLD") ? atoi(getenv("BBME_WIDE_THRESHOLD")) : 16;
-    a.wide_threshold = (uint32_t)std::max(4, wide_env);
+    a.local_rounds = c->local_rounds;
+    a.wide_threshold = (uint32_t)c->wide_threshold;
     // every round of a wave either empties part of its queue or follows a real change, and a change can only travel
     // along the raster dependency chain (< 2 * rows + cols blocks): the cap is an exit every wave reaches even if
     // that reasoning were wrong; hitting it raises counters[5] and the result is refused (BBME_ERR_STATE)
     a.round_cap = c->round_cap > 0 ? (uint32_t)c->round_cap : 64u * (uint32_t)(2 * a.rows + a.cols + 16);
     a.counters = c->counters;
+    a.stats = stats ? 1 : 0;
+    // the SAD memo: sweeps at b >= 8 whose pass 1 runs in the chain form (it is what fills the slots); the first sweep at a
+    // (level, block size) finds nothing in it and rewrites every slot
+    const long long nblk_memo = (long long)a.rows * a.cols;
+    if (c->use_memo && c->memo && !c->jacobi && b >= c->memo_min_block && nblk_memo <= c->pass1_lanes_max && (size_t)nblk_memo <= c->memo_blocks &&
+        L.width <= 8192 && L.height <= 8192) {             // (group_sads packs a vector into 2 x 14 bits)
+        a.memo = c->memo;
+        a.s_memo = c->memo_stride;
+        a.memo_init = !(c->memo_level == level && c->memo_block == b);
+        a.memo_forward = c->memo_forward ? 1 : 0;
+        c->memo_level = level; c->memo_block = b;
+    }
     // relaxation launches (k_reg_iter, 8 local rounds per tile): one more launch (>= 5 us), which only the sweeps with
     // heavy first generations repay -- measured on cfg3 / cfg4 / cfg2: large grids of small blocks, one launch per sweep
     const long long nblk = (long long)a.rows * a.cols;
@@ -432,6 +466,7 @@ int enqueue_pyramid(bbme_ctx *c, bool speculate)
         HIP_TRY(hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, lo));
     }
     bool speculated = false;
+    c->memo_block = 0;                                  // a captured launch sequence must not depend on what ran before it
     for (int l = nl - 1; l >= 0; --l) {
         if (speculated) {
             HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
@@ -467,6 +502,7 @@ int profiled_pyramid(bbme_ctx *c)
     std::vector<int> kind;   // 0 search, 1 reg, 2 expand ; section i lies between ev[i] and ev[i+1]
     std::vector<int> lvl;
     if (int rc = mark()) return rc;
+    c->memo_block = 0;
     for (int l = (int)c->lv.size() - 1; l >= 0; --l) {
         if (int rc = launch_search(c, l)) return rc;
         if (int rc = mark()) return rc;
@@ -553,6 +589,11 @@ int bbme_create_batch(const bbme_params *params, int width, int height, int devi
         if (const char *e = getenv("BBME_SPEC_MIN_GABS")) c->spec_min_absdiffs = atof(e) * 1e9;
     }
     if (const char *e = getenv("BBME_GENERIC_SEARCH")) c->force_generic_search = atoi(e) != 0;
+    if (const char *e = getenv("BBME_LOCAL_ROUNDS")) c->local_rounds = std::max(1, atoi(e));
+    if (const char *e = getenv("BBME_WIDE_THRESHOLD")) c->wide_threshold = std::max(4, atoi(e));
+    if (const char *e = getenv("BBME_MEMO")) c->use_memo = atoi(e) != 0;
+    if (const char *e = getenv("BBME_MEMO_FORWARD")) c->memo_forward = atoi(e) != 0;
+    if (const char *e = getenv("BBME_MEMO_MIN_B")) c->memo_min_block = std::max(8, atoi(e));
     if (const char *e = getenv("BBME_XCD_REMAP")) c->xcd_remap = atoi(e) != 0;
     c->lv.resize(nl);
     auto cleanup_fail = [&](int rc) { bbme_destroy(c); return rc; };
@@ -567,6 +608,11 @@ int bbme_create_batch(const bbme_params *params, int width, int height, int devi
         Level &L = c->lv[l];
         L.width = g.padded_width >> l; L.height = g.padded_height >> l;
         L.block = params->block_size[l]; L.search = params->search_size[l];
+        // the memo serves the sweeps at b >= memo_min_block whose grid the chain-form pass 1 takes: room for the largest of them
+        for (int b = c->memo_min_block; b <= L.block; b <<= 1) {
+            const size_t nb = (size_t)(L.width / b) * (L.height / b);
+            if ((long long)nb <= c->pass1_lanes_max) { c->memo_blocks = std::max(c->memo_blocks, nb); break; }
+        }
         SpiralTable sp = build_spiral(L.search, L.block);
         L.range = sp.range; L.ncand = (int)sp.dx.size();
         L.pitch_dw = (L.block + 2 * L.range) / 4 + 2;
@@ -678,6 +724,13 @@ int bbme_create_batch(const bbme_params *params, int width, int height, int devi
         (err = hipMemset(c->counters, 0, P * 256)) != hipSuccess ||
         (err = hipMemset(c->flow, 0, flow_bytes)) != hipSuccess)
         return cleanup_fail(bbme::fail(BBME_ERR_HIP, "allocating work buffers: %s", hipGetErrorString(err)));
+    if (c->use_memo && c->memo_blocks) {
+        c->memo_stride = (uint32_t)round64(c->memo_blocks << kMemoSlotShift);
+        // every slot starts as "nothing known" (the MV half of the word is what counts: 0x80008000 is never a motion vector)
+        if ((err = hipMalloc(&c->memo, P * c->memo_stride * sizeof(unsigned long long))) != hipSuccess ||
+            (err = hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(c->memo), (int)kMemoNoMv, P * c->memo_stride * 2)) != hipSuccess)
+            return cleanup_fail(bbme::fail(BBME_ERR_HIP, "allocating the SAD memo: %s", hipGetErrorString(err)));
+    }
     HIP_TRY(hipDeviceSynchronize());
     bbme::clear_error();
     *out = c;
@@ -705,6 +758,7 @@ int bbme_destroy(bbme_ctx *c)
     (void)hipFree(c->own);
     (void)hipFree(c->flags[0]); (void)hipFree(c->flags[1]);
     (void)hipFree(c->counters);
+    (void)hipFree(c->memo);
     if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -884,6 +938,7 @@ int bbme_set_frames_device_pair(bbme_ctx *c, int pair, const uint8_t *d_image1, 
     }
     HIP_TRY(hipGetLastError());
     c->frames_mask |= 1ull << pair;
+    c->memo_block = 0;                                  // new planes: what the SAD memo holds is no longer true
     return BBME_OK;
 }
 
@@ -893,6 +948,7 @@ int bbme_level_planes_device(bbme_ctx *c, int level, uint8_t **d1, uint8_t **d2)
     if (d1) *d1 = c->lv[level].img1;
     if (d2) *d2 = c->lv[level].img2;
     c->frames_mask |= 1ull;        // the caller fills them in place (pair 0)
+    c->memo_block = 0;
     return BBME_OK;
 }
 
@@ -906,6 +962,7 @@ int bbme_set_level_planes_host(bbme_ctx *c, int level, const uint8_t *image1, co
     HIP_TRY(hipMemcpyAsync(L.img2, image2, (size_t)L.width * L.height, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->frames_mask |= 1ull;
+    c->memo_block = 0;
     return BBME_OK;
 }
 
@@ -925,8 +982,8 @@ int bbme_estimate(bbme_ctx *c)
     if (int rc = check_ctx(c)) return rc;
     if (!c->frames_set()) return bbme::fail(BBME_ERR_STATE, "bbme_estimate: no frames set (every pair of a batch needs its frames)");
     HIP_TRY(hipSetDevice(c->device));
-    if (c->profiling) return profiled_pyramid(c);
-    if (!c->use_graph) return enqueue_pyramid(c, c->speculate);
+    if (c->profiling) { const int rc = profiled_pyramid(c); c->memo_block = 0; return rc; }
+    if (!c->use_graph) { const int rc = enqueue_pyramid(c, c->speculate); c->memo_block = 0; return rc; }
     if (!c->graph_exec) {
         // the launch sequence is fixed (no host decisions inside), so capture it once
         hipGraph_t graph = nullptr;
@@ -943,6 +1000,8 @@ int bbme_estimate(bbme_ctx *c)
         for (Level &L : c->lv) { L.cur_grid = L.final_grid(); L.cur_block = 2; }
     }
     HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
+    // after a pyramid the memo describes level 0 at its last memoised block size; a later stage call starts afresh
+    c->memo_block = 0;
     return BBME_OK;
 }
 
@@ -1081,7 +1140,7 @@ int bbme_stage_regularize(bbme_ctx *c, int level, int block, int mult)
     if (int rc = check_level(c, level)) return rc;
     if (!c->frames_set()) return bbme::fail(BBME_ERR_STATE, "no frames set");
     HIP_TRY(hipSetDevice(c->device));
-    return launch_sweep(c, level, block, mult);
+    return launch_sweep(c, level, block, mult, true);       // with the solver's counters (bbme_sweep_stats)
 }
 
 int bbme_stage_get_mvs(bbme_ctx *c, int level, int block, int16_t *mvs)

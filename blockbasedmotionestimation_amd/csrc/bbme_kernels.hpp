@@ -784,8 +784,14 @@ struct RegArgs {
     uint32_t *counters;         // [0..2] overflow list lengths (rotating), [3] safety-net passes, [4] blocks re-evaluated,
                                 // [5] sticky: a sweep hit a cap without converging, [6] solver ticket, [7] most rounds of
                                 // one wave, [8] rounds summed, [9..15] phase profile
+    // SAD memo (see "SAD memo" below): nine (MV, SAD) pairs per block, or nullptr when the sweep runs without one
+    unsigned long long *memo;
+    int memo_init;              // 1: the memo holds nothing for this (level, block size) yet -- pass 1 writes every slot and reads none
+    int memo_forward;           // 1: a block that changes leaves its dependants' SADs of the new value in their slots (forward_sads)
+    int stats;                  // 1: the solver's waves add their counts to counters[4], [7..12] -- stage calls only: several hundred
+                                // waves adding to the same few words is a queue at the memory side that the pyramid need not stand in
     // batch (blockIdx.y = pair): element strides from pair to pair of the per-pair buffers; counters: 64 words
-    uint32_t s_plane, s_old, s_est, s_list, s_own, s_flag;
+    uint32_t s_plane, s_old, s_est, s_list, s_own, s_flag, s_memo;
 };
 __device__ __forceinline__ void shift_pair(RegArgs &a, uint32_t p)
 {
@@ -795,6 +801,7 @@ __device__ __forceinline__ void shift_pair(RegArgs &a, uint32_t p)
     a.own += (size_t)p * a.s_own;
     if (a.flag_cur) a.flag_cur += (size_t)p * a.s_flag;
     if (a.flag_next) a.flag_next += (size_t)p * a.s_flag;
+    if (a.memo) a.memo += (size_t)p * a.s_memo;
     a.counters += (size_t)p * 64u;
 }
 
@@ -1051,20 +1058,151 @@ __device__ __forceinline__ LaneCand lanes_candidate(const RegArgs &a, int r, int
     return lc;
 }
 
-// Second half: lane k16 of the group holds candidate k16's MV `mv`; every lane of the group returns the winner.
-template <int BS>
-__device__ __forceinline__ mv_t lanes_score(const RegArgs &a, int r, int c, int k16, bool present, mv_t mv,
-                                            PhaseProf *prof = nullptr)
+// ---- SAD memo -------------------------------------------------------------------------------
+// The reference memoises block SADs in `fast_array` (motion_framework.h:46, .cpp:594-602: a hit returns what :599 would
+// recompute).  Here, for the block sizes whose SAD is worth keeping (b >= 8), every block owns one slot per candidate:
+// (MV, SAD(block, MV)) of that candidate at its last evaluation.  SAD(block, MV) is a pure function of the two level planes
+// and the block size, so a slot is a FACT, not state: whoever wrote it and whenever, a slot whose MV equals the
+// candidate's MV carries that candidate's SAD.  That is what makes the memo safe under the solver's asynchrony -- slots
+// are single 8-byte words (never torn), a stale or overwritten slot is still true (so the words need no coherence beyond
+// the XCD's L2), and the only obligation is that no slot survives a change of (planes, block size): the first pass 1 at a
+// block size (RegArgs::memo_init) rewrites every slot, and kernel boundaries write every L2 back.
+// A chain round on a lone wave costs what it ISSUES (~5 cycles an instruction) plus its dependent memory trips, so the memo
+// is used the cheapest way: candidate k looks at slot k only (one compare), else at slot 0 (the block's own vector: in a
+// region about to be flooded all the other candidates equal it); what is still unknown is summed by the lane group, one
+// image row per lane; and a block that changes leaves SAD(dependant, new MV) in the slot through which each of its
+// dependants R, DR, D, DL will see the new value (forward_sads) -- computed while its own store drains, so that the
+// re-evaluation the change triggers, the next link of the chain, touches no image row at all.
+constexpr uint32_t kMemoNoMv = 0x80008000u;       // (-32768, -32768): never a motion vector
+constexpr uint32_t kMemoNoSad = 0xffffffffu;      // "not known": every real SAD is below 255 * 64 * 64
+constexpr int kMemoSlotShift = 4;                  // 16 words (one 128-byte line) per block, nine used
+// what the solver's chain rounds found in the memo (wave-uniform sums; bbme_sweep_stats words 9..12, unless the build is a
+// phase-profile build, which keeps its cycle counts there)
+struct MemoStats { uint32_t lookups = 0, misses = 0, passes = 0, forwards = 0; };
+
+// Memo words are read and written through a raw buffer descriptor, which is what carries the cache policy wanted here:
+// the solver's loads miss the (per-CU, incoherent) L1 and are served by the XCD's L2 (sc0), stores are plain write-throughs
+// to that L2.  Nothing is forced out to the memory side as the estimates are: the solver deals a band of the raster to each
+// XCD, so a block's slots are read where they were written; a wave of another XCD sees older words -- still facts -- and a
+// store that had to complete at the memory side (sc1) would sit in front of the round's atomics on the in-order counter.
+typedef uint32_t memo_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t memo_rsrc(const RegArgs &a)
 {
-#pragma clang fp contract(off)
+    return __builtin_amdgcn_make_buffer_rsrc(a.memo, 0, 0x7fffffff, 0x00020000);
+}
+template <bool COHERENT>
+__device__ __forceinline__ uint2 memo_load(const RegArgs &a, uint32_t word)
+{
+    const memo_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(memo_rsrc(a), (int)(word * 8u), 0, COHERENT ? 1 : 0);
+    return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ void memo_store(const RegArgs &a, uint32_t word, uint32_t mv, uint32_t sad)
+{
+    const memo_u32x2 v = {mv, sad};
+    __builtin_amdgcn_raw_buffer_store_b64(v, memo_rsrc(a), (int)(word * 8u), 0, 0);
+}
+
+// LPM lanes of a 16-lane group share the pixels of one BS x BS block (and one motion vector): 16 / LPM blocks at a time.
+// A lane takes whole rows (sub, sub + LPM, ...) or, with more lanes than rows (b = 8 on 16 lanes), one part of a row.
+template <int BS, int LPM> struct GroupSad {
+    static_assert(LPM == 4 || LPM == 8 || LPM == 16, "lanes per block");
+    static constexpr int PARTS = LPM > BS ? LPM / BS : 1;      // lanes per row
+    static constexpr int RPL = LPM > BS ? 1 : BS / LPM;        // rows per lane
+    static constexpr int NW = BS / 4 / PARTS;                  // dwords per lane and row
+    static_assert(NW >= 1, "a lane needs at least a dword");
+    struct __attribute__((packed, aligned(1))) row_t { uint32_t v[NW]; };
+    static __device__ __forceinline__ void load(const uint8_t *img, int width, int x, int y, int sub, row_t (&rows)[RPL])
+    {
+        const int row = PARTS > 1 ? sub / PARTS : sub, col = PARTS > 1 ? (sub % PARTS) * 4 * NW : 0;
+        const uint8_t *p = img + (uint32_t)((y + row) * width + x + col);
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) rows[i] = *reinterpret_cast<const row_t *>(p + (uint32_t)(i * LPM * width));
+    }
+    // sum of absolute differences of the lane's pixels, reduced over the LPM lanes: every one of them returns the block's SAD
+    static __device__ __forceinline__ uint32_t reduce(const row_t (&u)[RPL], const row_t (&w)[RPL])
+    {
+        uint32_t s0 = 0, s1 = 0;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i)
+#pragma unroll
+            for (int q = 0; q < NW; ++q) {
+                if ((i + q) & 1) s1 = __builtin_amdgcn_sad_u8(u[i].v[q], w[i].v[q], s1);
+                else s0 = __builtin_amdgcn_sad_u8(u[i].v[q], w[i].v[q], s0);
+            }
+        uint32_t s = s0 + s1;
+        s += dpp_row<0xB1>(s);
+        s += dpp_row<0x4E>(s);
+        if constexpr (LPM >= 8) s += dpp_row<0x141>(s);
+        if constexpr (LPM >= 16) s += dpp_row<0x140>(s);
+        return s;
+    }
+};
+
+// SADs of the candidates the memo does not know, summed by the group, one vector per pass: the lowest lane in need names it
+// (a row minimum of lane << 28 | vector, four DPP steps -- vectors are below 2^13 in magnitude wherever the memo is used,
+// which the host checks), the 16 lanes take a row (or several) each, every lane holding that vector takes the sum.  The
+// loop is wave-uniform and ends when no lane of the wave needs one.
+template <int BS>
+__device__ __forceinline__ uint32_t group_sads(const RegArgs &a, int bx, int by, int k16, bool need, mv_t mv, uint32_t sad,
+                                               MemoStats *stats = nullptr)
+{
+    using G = GroupSad<BS, 16>;
+    typename G::row_t cur[G::RPL];
+    G::load(a.image1, a.width, bx, by, k16, cur);
+    const uint32_t packed = (mv & 0x3fffu) | ((mv >> 2) & 0x0fffc000u);      // 14 bits of dx, 14 bits of dy
+    do {
+        uint32_t key = need ? ((uint32_t)k16 << 28) | packed : 0xffffffffu;
+        key = min(key, dpp_row<0xB1>(key)); key = min(key, dpp_row<0x4E>(key));
+        key = min(key, dpp_row<0x141>(key)); key = min(key, dpp_row<0x140>(key));
+        const bool mine = need && ((key ^ packed) & 0x0fffffffu) == 0u;
+        // a group without a lane in need (key = -1) reads the block's own position: dx = dy = 0 after the mask below
+        const bool any = key != 0xffffffffu;
+        const int dx = any ? ((int)(key << 18) >> 18) : 0, dy = any ? ((int)(key << 4) >> 18) : 0;
+        typename G::row_t win[G::RPL];
+        G::load(a.image2, a.width, bx + dx, by + dy, k16, win);
+        const uint32_t s = G::reduce(cur, win);
+        if (mine) { sad = s; need = false; }
+        if (stats) stats->passes += 1;
+    } while (__ballot(need));
+    return sad;
+}
+
+// A block took the value `res`: leave SAD(dependant, res) in the slot through which each of its dependants R, DR, D, DL
+// will see it (candidate L, UL, U, UR of theirs).  Called between the estimate's store and the wait for it: the image
+// rows travel while the store drains.  `go`: the group's block changed (group-uniform); r, c, res are the group's.
+// b <= 16: the four quads of the group take one dependant each, a quarter of its rows per lane -- one pass.
+template <int BS>
+__device__ __forceinline__ void forward_sads(const RegArgs &a, int r, int c, int k16, bool go, mv_t res)
+{
+    constexpr int LPM = BS <= 16 ? 4 : 16;
+    using G = GroupSad<BS, LPM>;
+    constexpr int PER = 16 / LPM;                                          // dependants per pass
+#pragma unroll
+    for (int d0 = 0; d0 < 4; d0 += PER) {
+        const int d = d0 + (PER == 4 ? (k16 >> 2) : 0);                    // (0,+1) (+1,+1) (+1,0) (+1,-1)
+        const int tr = r + (d != 0), tc = c + (d < 2 ? 1 : 2 - d);
+        const int bx = tc * BS, by = tr * BS;
+        const int x2 = bx + mv_x(res), y2 = by + mv_y(res);
+        const bool ok = go && tr < a.rows && tc >= 0 && tc < a.cols &&
+                        !(x2 < 0 || x2 > a.width - BS || y2 < 0 || y2 > a.height - BS);
+        typename G::row_t u[G::RPL], w[G::RPL];
+        G::load(a.image1, a.width, ok ? bx : 0, ok ? by : 0, k16 & (LPM - 1), u);
+        G::load(a.image2, a.width, ok ? x2 : 0, ok ? y2 : 0, k16 & (LPM - 1), w);
+        const uint32_t s = G::reduce(u, w);
+        const uint32_t slot = d == 0 ? 1u : d == 1 ? 4u : d == 2 ? 6u : 5u;   // R sees it as L, DR as UL, D as U, DL as UR
+        if (ok && (k16 & (LPM - 1)) == 0)
+            memo_store(a, (((uint32_t)(tr * a.cols + tc)) << kMemoSlotShift) | slot, res, s);
+    }
+}
+
+// SAD of this lane's candidate, every row walked by the lane itself (no memo): the rows are independent loads, issued
+// back to back
+template <int BS>
+__device__ __forceinline__ uint32_t lane_sad(const RegArgs &a, int bx, int by, int x2, int y2)
+{
     constexpr int NW = BS >= 4 ? BS / 4 : 1;
     struct __attribute__((packed, aligned(1))) row_t { uint32_t v[NW]; };
     constexpr uint32_t kMask = BS >= 4 ? 0xffffffffu : 0x0000ffffu;
-    const int bx = c * BS, by = r * BS;
-    int x2 = bx + mv_x(mv), y2 = by + mv_y(mv);
-    const bool inside = present && !(x2 < 0 || x2 > a.width - BS || y2 < 0 || y2 > a.height - BS);   // :578
-    if (!inside) { x2 = bx; y2 = by; }
-    // SAD of this lane's candidate: the rows are independent loads, issued back to back
     uint32_t sad0 = 0, sad1 = 0;                              // two chains: v_sad_u8 results feed the next one
     const uint8_t *p1 = a.image1 + (size_t)by * a.width + bx;
     const uint8_t *p2 = a.image2 + (size_t)y2 * a.width + x2;
@@ -1087,7 +1225,42 @@ __device__ __forceinline__ mv_t lanes_score(const RegArgs &a, int r, int c, int 
             }
         if constexpr (BS >= 32) asm volatile("" ::: "memory");   // keep the chunks apart
     }
-    const uint32_t sad = sad0 + sad1;
+    return sad0 + sad1;
+}
+
+// Second half: lane k16 of the group holds candidate k16's MV `mv`; every lane of the group returns the winner.
+// MEMO: `memo` is what the lane's slot held (slot k16; lanes 9..15 shadow slot 0) and `slot` where it lives.
+template <int BS, bool MEMO = false, bool COHERENT = false, bool GROUP = (COHERENT || BS >= 32)>
+__device__ __forceinline__ mv_t lanes_score(const RegArgs &a, int r, int c, int k16, bool present, mv_t mv,
+                                            PhaseProf *prof = nullptr, uint2 memo = make_uint2(0, 0),
+                                            uint32_t slot = 0, MemoStats *stats = nullptr)
+{
+#pragma clang fp contract(off)
+    const int bx = c * BS, by = r * BS;
+    int x2 = bx + mv_x(mv), y2 = by + mv_y(mv);
+    const bool inside = present && !(x2 < 0 || x2 > a.width - BS || y2 < 0 || y2 > a.height - BS);   // :578
+    if (!inside) { x2 = bx; y2 = by; }
+    uint32_t sad;
+    if constexpr (MEMO) {
+        // slot k knows candidate k's SAD if it holds candidate k's vector; else slot 0 may (the block's own vector)
+        sad = memo.x == mv ? memo.y : kMemoNoSad;
+        {
+            const uint32_t m0 = dpp_row<0x150>(memo.x), s0 = dpp_row<0x150>(memo.y);
+            sad = (sad == kMemoNoSad && m0 == mv) ? s0 : sad;
+        }
+        const bool need = inside && sad == kMemoNoSad;
+        const unsigned long long nball = __ballot(need);
+        if (stats) { stats->lookups += (uint32_t)__popcll(__ballot(inside)); stats->misses += (uint32_t)__popcll(nball); }
+        if (nball) {
+            if constexpr (GROUP) sad = group_sads<BS>(a, bx, by, k16, need, mv, sad, stats);
+            else if (need) sad = lane_sad<BS>(a, bx, by, x2, y2);           // pass 1 at b <= 16: any number of different vectors in one trip
+        }
+        // the slot now describes this lane's candidate (or nothing, if it has no SAD); written only when that is news
+        const uint32_t nmv = inside ? mv : kMemoNoMv, nsad = inside ? sad : 0u;
+        if (k16 < 9 && (a.memo_init || nmv != memo.x || nsad != memo.y)) memo_store(a, slot, nmv, nsad);
+    } else {
+        sad = lane_sad<BS>(a, bx, by, x2, y2);
+    }
     BBME_PHASE(prof, 1);                                      // row loads + SAD
     // smoothness: sum over the present candidates of |u_m - u_k| + |v_m - v_k| (:637-641).  The group is
     // one DPP row of 16 lanes: candidate m reaches every lane by row_newbcast (a VALU move, no LDS trip)
@@ -1137,18 +1310,30 @@ __device__ __forceinline__ mv_t lanes_score(const RegArgs &a, int r, int c, int 
     return winner;
 }
 
-template <int BS, bool COHERENT>
+template <int BS, bool COHERENT, bool MEMO = false>
 __device__ __forceinline__ mv_t eval_block_lanes(const RegArgs &a, int r, int c, int k16, uint32_t use_new,
-                                                 PhaseProf *prof = nullptr, const LaneGeom *lg = nullptr)
+                                                 PhaseProf *prof = nullptr, const LaneGeom *lg = nullptr, MemoStats *stats = nullptr)
 {
     const LaneCand lc = lg ? lanes_candidate(a, *lg, r, c) : lanes_candidate(a, r, c, k16, use_new);
+    uint32_t slot = 0;                                        // the lane's memo word (index into RegArgs::memo)
+    uint2 memo = make_uint2(kMemoNoMv, 0u);
+    if constexpr (MEMO) {
+        // the memo slot rides in the candidates' memory trip
+        slot = (((uint32_t)(r * a.cols + c)) << kMemoSlotShift) | (uint32_t)(k16 < 9 ? k16 : 0);
+        if (!a.memo_init) memo = memo_load<COHERENT>(a, slot);
+    }
     const mv_t mv = load_est<COHERENT>(lc.src);
     BBME_PHASE(prof, 0);                                      // queue pop + address arithmetic + gather trip
     // every block of the round has nine equal candidates (behind a flood that has passed): equal SADs, equal smoothness, the
     // first one -- the block's own MV -- stays (:648-660), as in eval_block; no image row is touched
     const mv_t own = dpp_row<0x150>(mv);
-    if (!__ballot(lc.present && mv != own)) return own;
-    return lanes_score<BS>(a, r, c, k16, lc.present, mv, prof);
+    if (!__ballot(lc.present && mv != own)) {
+        if constexpr (MEMO) {
+            if (a.memo_init && k16 < 9) memo_store(a, slot, kMemoNoMv, 0u);   // nothing known yet
+        }
+        return own;
+    }
+    return lanes_score<BS, MEMO, COHERENT>(a, r, c, k16, lc.present, mv, prof, memo, slot, stats);
 }
 
 // ---- work-list state ---------------------------------------------------------------------
@@ -1257,7 +1442,7 @@ __global__ __launch_bounds__(256) void k_reg_pass1(RegArgs a)
 // read once, at the start; if its owner changes it during this launch, that owner marks the reader in flag_next.
 // Pass 1 in the chain form (16 lanes per block, lane k = candidate k), for grids too small to fill the chip: there the launch
 // lasts as long as one wave's instruction stream does, and the chain form's is a third as long as eval_block's.
-template <int BS>
+template <int BS, bool MEMO = false>
 __global__ __launch_bounds__(256) void k_reg_pass1_lanes(RegArgs a)
 {
     __builtin_amdgcn_s_setprio(2);
@@ -1268,7 +1453,7 @@ __global__ __launch_bounds__(256) void k_reg_pass1_lanes(RegArgs a)
     const int k16 = (int)(t & 15);
     if (g >= (long long)a.rows * a.cols) return;              // whole groups drop out together
     const int r = (int)(g / a.cols), c = (int)(g % a.cols);
-    const mv_t res = eval_block_lanes<BS, false>(a, r, c, k16, 0u);
+    const mv_t res = eval_block_lanes<BS, false, MEMO>(a, r, c, k16, 0u);
     if (k16 == 0) {
         a.est[g] = res;
         const mv_t old = a.old_grid[(size_t)(r >> a.old_shift) * a.old_cols + (c >> a.old_shift)];
@@ -1459,7 +1644,7 @@ __device__ __forceinline__ void drain_lists(const RegArgs &a, int t, int nthread
 // s belongs to wave s mod W of that XCD, so that a cluster of stale blocks is spread over many waves
 // instead of queueing up behind one, and a wave looks at 64 of its segments -- 1024 flags -- per memory
 // trip: a sweep that left nothing stale costs two trips at 2 M blocks, not 127.
-template <int BS, int SEG = 16>
+template <int BS, int SEG = 16, bool MEMO = false>
 __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
 {
     static_assert(SEG == 16 || SEG == 4, "flags per scan segment");
@@ -1512,6 +1697,7 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
     };
 
     const LaneGeom lgeom = lanes_geometry(a, lane & 15, BBME_NEW_MASK);      // chain form: lane k of a group = candidate k
+    MemoStats mstats;
 
     for (uint32_t k = 0;; ++k) {
         if (seg_begin + k * 64u * Wx + wx < seg_end) {
@@ -1566,9 +1752,19 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
                 if (leader) prev = load_est<true>(a.est + x);          // issued with the candidate loads
                 mv_t res;
                 if (wide) res = eval_block<BS, true>(a, r, c, sub, BBME_NEW_MASK);
-                else res = eval_block_lanes<BS, true>(a, r, c, sub, BBME_NEW_MASK, prof, &lgeom);
+                else res = eval_block_lanes<BS, true, MEMO>(a, r, c, sub, BBME_NEW_MASK, prof, &lgeom, MEMO ? &mstats : nullptr);
                 changed = leader && res != prev;
                 if (changed) __hip_atomic_store(a.est + x, res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if constexpr (MEMO) {
+                    // the dependants' SADs of the new value, while the store drains
+                    if (!wide && a.memo_forward) {
+                        const unsigned long long cb = __ballot(changed);
+                        if (cb) {
+                            forward_sads<BS>(a, r, c, sub, dpp_row<0x150>((uint32_t)changed) != 0, res);
+                            mstats.forwards += (uint32_t)__popcll(cb);
+                        }
+                    }
+                }
             }
             evaluated += cnt;
             if (__ballot(changed)) BBME_DRAIN();                       // the stores have completed
@@ -1649,7 +1845,15 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
     if (lane == 0 && prof_s.ph[6])
         for (int i = 0; i < 7; ++i) atomicAdd(&a.counters[9 + i], prof_s.ph[i]);
 #endif
-    if (lane == 0 && evaluated) { atomicAdd(&a.counters[4], evaluated); atomicMax(&a.counters[7], rounds); atomicAdd(&a.counters[8], rounds); }
+    if (a.stats && lane == 0 && evaluated) { atomicAdd(&a.counters[4], evaluated); atomicMax(&a.counters[7], rounds); atomicAdd(&a.counters[8], rounds); }
+#ifndef BBME_PHASE_PROFILE
+    if constexpr (MEMO) {
+        if (a.stats && lane == 0 && mstats.lookups) {
+            atomicAdd(&a.counters[9], mstats.lookups); atomicAdd(&a.counters[10], mstats.misses);
+            atomicAdd(&a.counters[11], mstats.passes); atomicAdd(&a.counters[12], mstats.forwards);
+        }
+    }
+#endif
 
     // epilogue: the workgroup that takes the last ticket knows every other one has finished (their
     // stores were drained before they took theirs) and empties the overflow list, if there is one

@@ -80,10 +80,20 @@ class MF:
             raise _capi.BbmeError(_capi.ERR_INVALID, "frames must keep the size the context was created for")
         _capi.check(self._lib.bbme_set_frames_host(self._ctx, image1.ctypes.data, image2.ctypes.data, self.orig_width))
 
+    def _check_device_frames(self, image1, image2):
+        """The padding kernel reads orig_height x pitch bytes behind each pointer: a tensor of any other shape must be
+        refused here (the C-ABI sees only a pointer and a pitch)."""
+        import torch
+        for t in (image1, image2):
+            if not (t.is_cuda and t.dtype == torch.uint8 and t.dim() == 2 and tuple(t.shape) == (self.orig_height, self.orig_width)):
+                raise _capi.BbmeError(_capi.ERR_INVALID, "device frames must be 2-D uint8 CUDA tensors of %d x %d (the size the "
+                                      "context was created for)" % (self.orig_height, self.orig_width))
+        if image1.stride(1) != 1 or image2.stride(1) != 1 or image1.stride(0) != image2.stride(0):
+            raise _capi.BbmeError(_capi.ERR_INVALID, "device frames must have unit column stride and a common row pitch")
+
     def set_frames_device(self, image1, image2):
         """Frames already in HBM (torch uint8 CUDA tensors, H x W): padding + pyramid on the GPU."""
-        assert image1.is_cuda and image2.is_cuda and image1.dtype.itemsize == 1
-        assert image1.stride(1) == 1 and image2.stride(1) == 1 and image1.stride(0) == image2.stride(0)
+        self._check_device_frames(image1, image2)
         self._torch_frames = (image1, image2)
         # the tensors may still be being written by work on torch's current stream: order the context's stream behind it
         import torch
@@ -271,9 +281,18 @@ class MFBatch(MF):
             raise _capi.BbmeError(_capi.ERR_INVALID, "frames must keep the size the context was created for")
         _capi.check(self._lib.bbme_set_frames_host_pair(self._ctx, pair, image1.ctypes.data, image2.ctypes.data, self.orig_width))
 
+    def set_frames(self, image1, image2):
+        """Pair 0 (the inherited entry point without a pair index)."""
+        self.set_pair(0, image1, image2)
+
+    def set_frames_device(self, image1, image2):
+        """Pair 0 (the inherited entry point without a pair index)."""
+        self.set_pair_device(0, image1, image2)
+
     def set_pair_device(self, pair, image1, image2):
-        assert image1.is_cuda and image2.is_cuda and image1.dtype.itemsize == 1
-        assert image1.stride(1) == 1 and image2.stride(1) == 1 and image1.stride(0) == image2.stride(0)
+        if not 0 <= pair < self.batch:
+            raise _capi.BbmeError(_capi.ERR_INVALID, "pair %d of a batch of %d" % (pair, self.batch))
+        self._check_device_frames(image1, image2)
         self._torch_frames[pair] = (image1, image2)
         import torch
         _capi.check(self._lib.bbme_wait_for_stream(self._ctx, C.c_void_p(torch.cuda.current_stream(image1.device).cuda_stream)))

@@ -248,7 +248,11 @@ int bbme_stage_set_mvs(bbme_ctx *ctx, int level, int block, const int16_t *mvs);
 int bbme_stage_expand(bbme_ctx *ctx);
 /* Raw counters of the last sweep (diagnostic, 16 words): [3] safety-net passes, [4] blocks
  * re-evaluated by the solver, [5] non-convergence flag, [7] most rounds run by one wave,
- * [8] rounds summed over waves. */
+ * [8] rounds summed over waves; sweeps with the SAD memo (block >= 8): [9] candidate look-ups
+ * of the chain rounds, [10] of them not in the memo, [11] group passes that summed those,
+ * [12] changes whose dependants' SADs were forwarded.  [4] and [7..12] are only counted by
+ * sweeps run through bbme_stage_regularize (hundreds of waves adding to the same words is a
+ * queue at the memory side that bbme_estimate does not stand in); [3] and [5] always. */
 int bbme_sweep_stats(bbme_ctx *ctx, unsigned *stats16);
 /* Fix-up passes the last sweep needed after its first full pass (diagnostic). */
 int bbme_last_sweep_passes(bbme_ctx *ctx, int *passes);

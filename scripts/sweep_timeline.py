@@ -31,4 +31,7 @@ for rep in range(2):
                     print("      LANES rounds=%d  cycles/round: gather %.0f  rows+sad %.0f  smooth+argmin %.0f  store+drain %.0f  "
                           "atomics %.0f  enqueue %.0f  | sum %.0f" % ((st[15],) + tuple(st[9 + i] / n for i in range(6))
                                                                      + (sum(st[9:15]) / n,)))
+                elif rep and st[9]:     # SAD memo (b >= 8): candidate look-ups of the chain rounds, how many the memo did not know, group passes
+                    print("      memo: look-ups %d  misses %d (%.1f%%)  group passes %d  forwarded changes %d"
+                          % (st[9], st[10], 100.0 * st[10] / st[9], st[11], st[12]))
             b >>= 1

@@ -46,6 +46,8 @@ CASES = {
     "hotpath_b8_r32_l2": (96, 64, [72, 72], [8, 8], 2003, 10),
     "hotpath_b32_r16_l2": (256, 128, [64, 64], [32, 32], 2004, 14),
     "hotpath_mixed_l3": (192, 128, [24, 40, 30], [8, 16, 8], 2005, 8),
+    # the reference's second literal set (main_class.cpp:15-17): block {16,16,32}, search {32,32,42}; 376 x 250 pads to 384 x 256
+    "hotpath_ref2_l3": (376, 250, [32, 32, 42], [16, 16, 32], 2006, 8),
 }
 
 
@@ -107,6 +109,9 @@ def main():
     if sys.argv[1:] == ["variants"]:
         for name, cfg in VARIANTS.items():
             make_hotpath(name, *cfg)
+        return
+    if len(sys.argv) == 3 and sys.argv[1] == "only":          # one hot-path case; the other files are not rewritten
+        make_hotpath(sys.argv[2], *{**CASES, **VARIANTS}[sys.argv[2]])
         return
     for name, cfg in CASES.items():
         make_hotpath(name, *cfg)

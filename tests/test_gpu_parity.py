@@ -58,6 +58,9 @@ CASES = [
     (384, 384, [158], [32], 1021, 60),                          # B=32, R=63 (largest supported)
     (384, 256, [134], [8], 1022, 60),                           # B=8, R=63
     (384, 256, [142], [16], 1023, 60),                          # B=16, R=63
+    # the author's second literal set (main_class.cpp:15-17, commented out there) on the 584 x 388 Middlebury geometry:
+    # 32 x 32 blocks over 16 x 16 ones (search_prediction's mixed-size path) and an odd shift, 42 - 32 = 10 -> R = 5
+    (584, 388, [32, 32, 42], [16, 16, 32], 1024, 10),
 ]
 
 
@@ -68,7 +71,7 @@ def test_stagewise_parity(bbme, oracle, w, h, search, block, seed, mm):
 
 
 @pytest.mark.parametrize("name", ["hotpath_b16_r7_l3", "hotpath_b16_r16_l2", "hotpath_b8_r32_l2",
-                                  "hotpath_b32_r16_l2", "hotpath_mixed_l3",
+                                  "hotpath_b32_r16_l2", "hotpath_mixed_l3", "hotpath_ref2_l3",
                                   "variant_raster_b16_r7_l3", "variant_raster_b8_r32_l2", "variant_jacobi_b16_r7_l3"])
 def test_golden_fixtures(bbme, name):
     """Committed vectors (tests/golden/*.npz): planes in, every intermediate MV grid and the final
@@ -846,3 +849,72 @@ def test_8k_pair_schedule_independence(bbme):
         del os.environ["BBME_SOLVE_WGS"], os.environ["BBME_SOLVE_WAVES"]
     assert np.array_equal(mf.calcMotionBlockMatching(), a)
     mf.close()
+
+
+def _flood_field(rows, cols, u, v, seeds, obstacles, rng):
+    """An MV grid for the memo test: value u everywhere, the frame's true motion v at a few seed blocks (it floods right and down
+    from each of them during a sweep), and obstacle blocks with other vectors (non-uniform neighbourhoods: their SADs are
+    memoised by pass 1, the uniform blocks' are not)."""
+    g = np.empty((rows, cols, 2), np.int16)
+    g[...] = u
+    for r, c in seeds:
+        g[r, c] = v
+    for _ in range(obstacles):
+        g[int(rng.integers(0, rows)), int(rng.integers(0, cols))] = (int(rng.integers(-3, 4)), int(rng.integers(-3, 4)))
+    return g
+
+
+@pytest.mark.parametrize("b", [8, 16, 32])
+def test_sad_memo_hits_and_misses(bbme, oracle, monkeypatch, b):
+    """The SAD memo of the regulariser's chain form (b >= 8) on content made for it: frame2 is frame1 moved by v, the field
+    holds u != v except at a few seeds, so v floods over the grid in ONE sweep -- every block behind the front is
+    re-evaluated as its L, UL, U, UR inputs change one, two or four at a time, the first time with SADs nobody has summed yet
+    (misses, summed by the lane group), later with SADs a neighbour's change forwarded or an earlier evaluation left (hits).
+    Both sweeps at the block size, against the oracle's raster sweep, with the memo off, on, on with forwarding, with a
+    one-wave solver (one wave re-uses its own slots round after round) and with wide rounds mixed in; the counters must show
+    that hits and misses both happened."""
+    rng = np.random.default_rng(900 + b)
+    rows, cols = 12, 18
+    h, w = rows * b, cols * b
+    f1 = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    v, u = (2, -1), (0, 0)
+    f2 = np.roll(f1, (v[1], v[0]), axis=(0, 1))                    # block at (x, y) of frame1 lies at (x + 2, y - 1) of frame2
+    search, block = [b + 8], [b]
+    fields = [_flood_field(rows, cols, u, v, [(1, 1)], 0, rng),                       # one flood, uniform territory
+              _flood_field(rows, cols, u, v, [(0, 0), (3, 9), (7, 2)], 6, rng),       # three fronts that meet, obstacles
+              _flood_field(rows, cols, v, u, [(2, 3)], 10, rng),                      # nothing to flood: obstacles only
+              rng.integers(-2, 3, (rows, cols, 2)).astype(np.int16)]                  # every neighbourhood different
+    lam = float(b // 2)
+    # (by default the memo serves b >= 16 and forwards nothing -- what measured fastest; the test takes it down to b = 8 and
+    # runs with and without forwarding)
+    for env in ({}, {"BBME_MEMO": "0"}, {"BBME_MEMO_FORWARD": "1"}, {"BBME_SOLVE_WGS": "1", "BBME_SOLVE_WAVES": "1"},
+                {"BBME_WIDE_THRESHOLD": "4", "BBME_MEMO_FORWARD": "1"}):
+        env = dict(env, BBME_MEMO_MIN_B="8")
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+        mf = bbme.MF(f1, f2, search, block, 1)
+        for k in env:
+            monkeypatch.delenv(k)
+        omf = oracle.OracleMF(f1, f2, search, block)
+        mf.set_level_planes(0, omf.image(0, 1), omf.image(0, 2))
+        lookups = misses = 0
+        for field in fields:
+            mf.stage_set_mvs(0, b, field)
+            omf.flow(0)[...] = 0
+            omf.flow(0)[::b, ::b, :] = field
+            omf.set_block_size(0, b)
+            omf.set_lambda(0, lam)
+            for mult in (1, 2):
+                mf.stage_regularize(0, b, mult)
+                omf.regularize_mvs(0, mult)
+                got, exp = mf.stage_get_mvs(0, b).astype(np.int32), omf.block_mvs(0, b)
+                assert np.array_equal(got, exp), "b=%d env=%s sweep %d: %d blocks differ" % (b, env, mult, int((got != exp).any(-1).sum()))
+                st = mf.sweep_stats()
+                lookups += st[9]; misses += st[10]
+        # the flood really happened (the test's premise), and the memo was exercised both ways
+        if env.get("BBME_MEMO") == "0":
+            assert lookups == 0
+        else:
+            assert lookups > 0 and 0 < misses < lookups, (b, env, lookups, misses)
+        mf.close()
+        omf.close()
