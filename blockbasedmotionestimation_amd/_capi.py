@@ -53,6 +53,9 @@ SIGNATURES = {
     "bbme_flo_read": (C.c_int, [C.c_char_p, _P(C.c_int), _P(C.c_int), _P(_P(C.c_float))]),
     "bbme_flo_write": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_void_p]),
     "bbme_flo_writer_create": (C.c_int, [_P(C.c_void_p)]),
+    "bbme_flo_writer_create_pool": (C.c_int, [C.c_int, _P(C.c_void_p)]),
+    "bbme_flo_writer_ticket": (C.c_int, [C.c_void_p, _P(C.c_ulonglong)]),
+    "bbme_flo_writer_wait_ticket": (C.c_int, [C.c_void_p, C.c_ulonglong]),
     "bbme_flo_writer_submit": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "bbme_flo_writer_submit_cells": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                                C.c_int, C.c_int]),

@@ -100,7 +100,7 @@ struct bbme_ctx {
     int local_rounds = 8;                         // k_reg_iter: heavy rounds of a tile per launch; BBME_LOCAL_ROUNDS
     int wide_threshold = 16;                      // solver: queue length above which a round takes the throughput form; BBME_WIDE_THRESHOLD
     int solve_waves = 4;                          // waves per solver workgroup (1, 2 or 4); BBME_SOLVE_WAVES
-    int solve_wgs = 128;                          // most workgroups of k_reg_solve (4 independent waves each): one wave per SIMD
+    int solve_wgs = 256;                          // most workgroups of k_reg_solve (4 independent waves each); r04: 256 measured 1.5 % ahead of 128 (one wave per SIMD)
     int xcd_remap = 1;                            // XCD-aware block order in k_search_fast; BBME_XCD_REMAP
     bool jacobi = false;                          // opt-in, not bit-exact: Jacobi sweeps (pass 1 only); bbme_set_regularizer_mode
     bool raster_search = false;                   // MF::find_min_block (:246-294) instead of the spiral search; bbme_set_search_mode
@@ -123,6 +123,16 @@ namespace {
 int check_ctx(const bbme_ctx *c)
 {
     if (!c) return bbme::fail(BBME_ERR_INVALID, "ctx is null");
+    return BBME_OK;
+}
+
+// The stage-by-stage entry points, the plane injection, the sweep counters, the device-side EPE and the RCCL gather address ONE
+// pair: on a batched context (bbme_create_batch with pairs > 1) they are refused rather than silently applied to pair 0.
+int single_pair_only(const bbme_ctx *c, const char *what)
+{
+    if (int rc = check_ctx(c)) return rc;
+    if (c->batch > 1)
+        return bbme::fail(BBME_ERR_UNSUPPORTED, "%s addresses one pair: not available on a batched context (%d pairs)", what, c->batch);
     return BBME_OK;
 }
 
@@ -575,6 +585,9 @@ int bbme_create_batch(const bbme_params *params, int width, int height, int devi
     if (const char *e = getenv("BBME_RELAX_STEPS")) c->relax_steps = std::max(0, std::min(64, atoi(e)));
     if (const char *e = getenv("BBME_SOLVE_WAVES")) { const int v = atoi(e); c->solve_waves = v <= 1 ? 1 : (v == 2 ? 2 : 4); }
     if (const char *e = getenv("BBME_TEST_ROUND_CAP")) c->round_cap = std::max(0, atoi(e));
+    // a batched context is throughput-bound (every launch carries several pairs): the chain form of pass 1, which trades
+    // instructions for latency, only pays on its small grids (24 pairs as 4 x 6: 53.7 -> 55.0 Mblocks/s)
+    if (pairs > 1) c->pass1_lanes_max = 40000;
     if (const char *e = getenv("BBME_PASS1_LANES_MAX")) c->pass1_lanes_max = atoll(e);
     if (const char *e = getenv("BBME_SCAN_FINE_MAX")) c->scan_fine_max = atoll(e);
     if (const char *e = getenv("BBME_SEARCH_SPLIT_BLOCKS")) { c->split_blocks = std::max(0, atoi(e)); c->split_forced = true; }
@@ -583,7 +596,7 @@ int bbme_create_batch(const bbme_params *params, int width, int height, int devi
     {
         // a speculative search may keep at most this many of its (one-wave) workgroups on a CU: the rest of the CU's wave
         // slots, registers and LDS (40 KB) stay free for the regulariser kernels it runs beside
-        int per_cu = 8;
+        int per_cu = 6;                                  // (r04: 6-7 measured best once the solver lost its counter atomics; 5 and 8 are 2 % slower)
         if (const char *e = getenv("BBME_SPEC_WGS_PER_CU")) per_cu = std::max(1, std::min(32, atoi(e)));
         c->spec_lds = ((size_t)(160 - 40) * 1024 / per_cu) / 256 * 256;
         if (const char *e = getenv("BBME_SPEC_MIN_GABS")) c->spec_min_absdiffs = atof(e) * 1e9;
@@ -944,6 +957,7 @@ int bbme_set_frames_device_pair(bbme_ctx *c, int pair, const uint8_t *d_image1, 
 
 int bbme_level_planes_device(bbme_ctx *c, int level, uint8_t **d1, uint8_t **d2)
 {
+    if (int rc = single_pair_only(c, "bbme_level_planes_device")) return rc;
     if (int rc = check_level(c, level)) return rc;
     if (d1) *d1 = c->lv[level].img1;
     if (d2) *d2 = c->lv[level].img2;
@@ -954,6 +968,7 @@ int bbme_level_planes_device(bbme_ctx *c, int level, uint8_t **d1, uint8_t **d2)
 
 int bbme_set_level_planes_host(bbme_ctx *c, int level, const uint8_t *image1, const uint8_t *image2)
 {
+    if (int rc = single_pair_only(c, "bbme_set_level_planes_host")) return rc;
     if (int rc = check_level(c, level)) return rc;
     if (!image1 || !image2) return bbme::fail(BBME_ERR_INVALID, "null plane");
     HIP_TRY(hipSetDevice(c->device));
@@ -968,6 +983,7 @@ int bbme_set_level_planes_host(bbme_ctx *c, int level, const uint8_t *image1, co
 
 int bbme_get_level_planes_host(bbme_ctx *c, int level, uint8_t *image1, uint8_t *image2)
 {
+    if (int rc = single_pair_only(c, "bbme_get_level_planes_host")) return rc;
     if (int rc = check_level(c, level)) return rc;
     HIP_TRY(hipSetDevice(c->device));
     Level &L = c->lv[level];
@@ -1096,6 +1112,7 @@ int bbme_expand_cells_device_on(bbme_ctx *c, const int16_t *d_cells, float *d_fl
 
 int bbme_calculate_mse_device(bbme_ctx *c, const float *d_gtruth, int gt_width, int gt_height, int scale, double *out)
 {
+    if (int rc = single_pair_only(c, "bbme_calculate_mse_device")) return rc;
     if (int rc = check_ctx(c)) return rc;
     if (!d_gtruth || !out || gt_width < 1 || gt_height < 1 || scale < 1)
         return bbme::fail(BBME_ERR_INVALID, "bbme_calculate_mse_device: bad arguments");
@@ -1129,6 +1146,7 @@ int bbme_calculate_mse_device(bbme_ctx *c, const float *d_gtruth, int gt_width, 
 
 int bbme_stage_search(bbme_ctx *c, int level)
 {
+    if (int rc = single_pair_only(c, "bbme_stage_search")) return rc;
     if (int rc = check_level(c, level)) return rc;
     if (!c->frames_set()) return bbme::fail(BBME_ERR_STATE, "no frames set");
     HIP_TRY(hipSetDevice(c->device));
@@ -1137,6 +1155,7 @@ int bbme_stage_search(bbme_ctx *c, int level)
 
 int bbme_stage_regularize(bbme_ctx *c, int level, int block, int mult)
 {
+    if (int rc = single_pair_only(c, "bbme_stage_regularize")) return rc;
     if (int rc = check_level(c, level)) return rc;
     if (!c->frames_set()) return bbme::fail(BBME_ERR_STATE, "no frames set");
     HIP_TRY(hipSetDevice(c->device));
@@ -1145,6 +1164,7 @@ int bbme_stage_regularize(bbme_ctx *c, int level, int block, int mult)
 
 int bbme_stage_get_mvs(bbme_ctx *c, int level, int block, int16_t *mvs)
 {
+    if (int rc = single_pair_only(c, "bbme_stage_get_mvs")) return rc;
     if (int rc = check_level(c, level)) return rc;
     Level &L = c->lv[level];
     if (!mvs) return bbme::fail(BBME_ERR_INVALID, "null output");
@@ -1169,6 +1189,7 @@ int bbme_stage_get_mvs(bbme_ctx *c, int level, int block, int16_t *mvs)
 
 int bbme_stage_set_mvs(bbme_ctx *c, int level, int block, const int16_t *mvs)
 {
+    if (int rc = single_pair_only(c, "bbme_stage_set_mvs")) return rc;
     if (int rc = check_level(c, level)) return rc;
     Level &L = c->lv[level];
     if (!mvs) return bbme::fail(BBME_ERR_INVALID, "null input");
@@ -1187,6 +1208,7 @@ int bbme_stage_set_mvs(bbme_ctx *c, int level, int block, const int16_t *mvs)
 
 int bbme_stage_expand(bbme_ctx *c)
 {
+    if (int rc = single_pair_only(c, "bbme_stage_expand")) return rc;
     if (int rc = check_ctx(c)) return rc;
     HIP_TRY(hipSetDevice(c->device));
     return launch_expand(c);
@@ -1194,6 +1216,7 @@ int bbme_stage_expand(bbme_ctx *c)
 
 int bbme_last_sweep_passes(bbme_ctx *c, int *passes)
 {
+    if (int rc = single_pair_only(c, "bbme_last_sweep_passes")) return rc;
     if (int rc = check_ctx(c)) return rc;
     if (!passes) return bbme::fail(BBME_ERR_INVALID, "null output");
     HIP_TRY(hipSetDevice(c->device));
@@ -1208,6 +1231,7 @@ int bbme_last_sweep_passes(bbme_ctx *c, int *passes)
 
 int bbme_sweep_stats(bbme_ctx *c, unsigned *stats)
 {
+    if (int rc = single_pair_only(c, "bbme_sweep_stats")) return rc;
     if (int rc = check_ctx(c)) return rc;
     if (!stats) return bbme::fail(BBME_ERR_INVALID, "null output");
     HIP_TRY(hipSetDevice(c->device));

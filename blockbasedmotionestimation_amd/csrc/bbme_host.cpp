@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <set>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -241,7 +242,8 @@ SearchPlan plan_search(int range, int block_size, int max_strip, int lanes)
     // search_aligned_column): kind 1, candidate row n - 1 of the G' full groups, four lanes per (group, row), a quarter of
     // the block's rows each; kind 2, candidate column n - 1 (dx = +R, dword aligned in the staged window: R is even),
     // one candidate per lane, v_sad_u8.  rounds[] = S | kind << 8.
-    const bool tight = n % 4 == 1 && n >= 9 && block_size <= 16 && !getenv("BBME_LOOSE_PLAN");
+    static const bool loose = getenv("BBME_LOOSE_PLAN") != nullptr;   // read once: every context of a process plans alike
+    const bool tight = n % 4 == 1 && n >= 9 && block_size <= 16 && !loose;
     const int groups_main = tight ? p.groups - 1 : p.groups, rows_main = tight ? n - 1 : n;
     std::vector<int> next(groups_main, 0);                   // first uncovered candidate row per column group
     auto emit_round = [&](int s, int want) {
@@ -595,14 +597,19 @@ struct bbme_flo_writer {
     struct Job {
         std::string name; int width, height; const float *data; size_t pitch_floats;
         const int16_t *cells; int cell_pitch, pad_x, pad_y;          // cells != nullptr: expand the 2x2-cell grid while writing
+        unsigned long long ticket;
     };
     std::mutex mu;
     std::condition_variable cv_job, cv_idle;
     std::deque<Job> jobs;
-    bool busy = false, stop = false;
+    bool stop = false;
     int status = BBME_OK;
     std::string error;
-    std::thread worker;
+    // tickets: job n is the n-th submitted (from 1); `finished` = every job up to it is on disk, `late` = finished jobs beyond
+    // a gap (a pool of workers finishes files out of order)
+    unsigned long long submitted = 0, finished = 0;
+    std::set<unsigned long long> late;
+    std::vector<std::thread> workers;
 };
 
 // copy_to_all_pixels (motion_framework.cpp:815-826) + the padding strip of main_class.cpp:63-70 + WriteFlowFile's rows, fused:
@@ -669,7 +676,6 @@ static void flo_writer_main(bbme_flo_writer *w)
         if (w->jobs.empty()) return;
         bbme_flo_writer::Job job = w->jobs.front();
         w->jobs.pop_front();
-        w->busy = true;
         lk.unlock();
         bool ok = false;
         if (job.cells) ok = flo_write_cells(job);
@@ -684,16 +690,20 @@ static void flo_writer_main(bbme_flo_writer *w)
         }
         lk.lock();
         if (!ok && w->status == BBME_OK) { w->status = BBME_ERR_IO; w->error = "WriteFlowFile: problem writing " + job.name; }
-        w->busy = false;
-        if (w->jobs.empty()) w->cv_idle.notify_all();
+        w->late.insert(job.ticket);
+        while (!w->late.empty() && *w->late.begin() == w->finished + 1) { w->late.erase(w->late.begin()); ++w->finished; }
+        w->cv_idle.notify_all();
     }
 }
 
-int bbme_flo_writer_create(bbme_flo_writer **out)
+int bbme_flo_writer_create(bbme_flo_writer **out) { return bbme_flo_writer_create_pool(1, out); }
+
+int bbme_flo_writer_create_pool(int workers, bbme_flo_writer **out)
 {
     if (!out) return bbme::fail(BBME_ERR_INVALID, "bbme_flo_writer_create: null output");
+    if (workers < 1 || workers > 64) return bbme::fail(BBME_ERR_INVALID, "bbme_flo_writer_create_pool: %d workers (1..64)", workers);
     bbme_flo_writer *w = new bbme_flo_writer();
-    w->worker = std::thread(flo_writer_main, w);
+    for (int i = 0; i < workers; ++i) w->workers.emplace_back(flo_writer_main, w);
     *out = w;
     return BBME_OK;
 }
@@ -709,7 +719,7 @@ int bbme_flo_writer_submit(bbme_flo_writer *w, const char *filename, int width, 
     if (strcmp(dot, ".flo") != 0) return bbme::fail(BBME_ERR_IO, "WriteFlowFile: filename should have extension '.flo'");
     {
         std::lock_guard<std::mutex> lk(w->mu);
-        w->jobs.push_back({filename, width, height, data, (size_t)pitch_pixels * 2, nullptr, 0, 0, 0});
+        w->jobs.push_back({filename, width, height, data, (size_t)pitch_pixels * 2, nullptr, 0, 0, 0, ++w->submitted});
     }
     w->cv_job.notify_one();
     return BBME_OK;
@@ -729,17 +739,27 @@ int bbme_flo_writer_submit_cells(bbme_flo_writer *w, const char *filename, int w
     if (strcmp(dot, ".flo") != 0) return bbme::fail(BBME_ERR_IO, "WriteFlowFile: filename should have extension '.flo'");
     {
         std::lock_guard<std::mutex> lk(w->mu);
-        w->jobs.push_back({filename, width, height, nullptr, 0, cells, cell_cols, pad_x, pad_y});
+        w->jobs.push_back({filename, width, height, nullptr, 0, cells, cell_cols, pad_x, pad_y, ++w->submitted});
     }
     w->cv_job.notify_one();
     return BBME_OK;
 }
 
-int bbme_flo_writer_wait(bbme_flo_writer *w)
+int bbme_flo_writer_ticket(bbme_flo_writer *w, unsigned long long *ticket)
+{
+    if (!w || !ticket) return bbme::fail(BBME_ERR_INVALID, "bbme_flo_writer_ticket: null argument");
+    std::lock_guard<std::mutex> lk(w->mu);
+    *ticket = w->submitted;
+    return BBME_OK;
+}
+
+int bbme_flo_writer_wait(bbme_flo_writer *w) { return bbme_flo_writer_wait_ticket(w, ~0ull); }
+
+int bbme_flo_writer_wait_ticket(bbme_flo_writer *w, unsigned long long ticket)
 {
     if (!w) return bbme::fail(BBME_ERR_INVALID, "bbme_flo_writer_wait: null writer");
     std::unique_lock<std::mutex> lk(w->mu);
-    w->cv_idle.wait(lk, [&] { return w->jobs.empty() && !w->busy; });
+    w->cv_idle.wait(lk, [&] { return w->finished >= std::min(ticket, w->submitted); });
     if (w->status != BBME_OK) {
         const int st = w->status;
         const std::string msg = w->error;
@@ -757,7 +777,7 @@ int bbme_flo_writer_destroy(bbme_flo_writer *w)
         w->stop = true;
     }
     w->cv_job.notify_all();
-    w->worker.join();                       // finishes the queued files first
+    for (std::thread &t : w->workers) t.join();      // they finish the queued files first
     delete w;
     return BBME_OK;
 }

@@ -213,7 +213,9 @@ __global__ __launch_bounds__(64) void k_search_generic(SearchArgs a)
 // owns one column group and a vertical STRIP of S consecutive candidate rows, so each window
 // row it reads from LDS (B/4 + 1 dwords) feeds up to S * B/4 QSADs.  The odd (2R+1)^2 candidate
 // square is cut by the host into "rounds" of up to 64 equal-height strips (S in 16,8,4,2,1) so
-// that lanes stay busy; `tasks` holds (g | dy0 << 8) per lane and round.
+// that lanes stay busy; `tasks` holds one word per lane and round: strip rounds g | dy0 << 8, and for the rim rounds of
+// the tight plan (even ranges; plan_search in bbme_host.cpp) g | dy << 8 | part << 16 (the last candidate row, four lanes
+// of a quad per (group, row), a quarter of the block's rows each) or a bare dy (the last candidate column, dx = +R).
 // Winner = min over (SAD << 16) | spiral_rank, i.e. lowest SAD, ties by the reference's visiting
 // order (motion_framework.cpp:326-411, strict < at :339); the rank of every (dx, dy) comes from a
 // table the host builds by walking that loop.  Candidates whose block leaves the image (:335) and
@@ -227,7 +229,8 @@ struct FastSearchArgs {
     const uint32_t *spiral;     // rank -> (dx & 0xffff) | (dy << 16)
     const uint16_t *rank_of;    // [(dy+R) * rank_pitch + (dx+R)] -> rank, 0xffff where dx > R
     int rank_pitch;             // multiple of 4
-    const uint32_t *tasks;      // nrounds * 64 entries: g | dy0 << 8, 0xffffffff = idle lane
+    const uint32_t *tasks;      // nrounds * 64 entries by round kind (rounds[] >> 8 & 0xff): 0 strips g | dy0 << 8; 1 last row
+                                // g | dy << 8 | part << 16; 2 last column dy; 0xffffffff = idle lane
     const uint32_t *rounds;     // nrounds entries: strip height S | kind << 8 | (strip rounds) first row of the round in lane_ranks << 16
     int nrounds;
     const uint2 *lane_ranks;    // strip rounds: the ranks of a lane's candidates, S entries of 4 x u16 (columns 4g..4g+3 of row dy0 + d),

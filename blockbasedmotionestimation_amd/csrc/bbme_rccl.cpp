@@ -22,7 +22,13 @@ extern "C" {
 int bbme_gather_cells(bbme_ctx *ctx, void *nccl_comm, int root, int32_t *d_recv)
 {
     if (!ctx || !nccl_comm) return BBME_ERR_INVALID;
-    int pw = 0, ph = 0;
+    int pw = 0, ph = 0, pairs = 1;
+    if (int rc = bbme_batch_size(ctx, &pairs)) return rc;
+    if (pairs > 1) {                              // one cell grid per rank: a batched context would silently ship pair 0 only
+        snprintf(g_err, sizeof g_err, "bbme_gather_cells: not available on a batched context (%d pairs)", pairs);
+        fprintf(stderr, "bbme_rccl: %s\n", g_err);
+        return BBME_ERR_UNSUPPORTED;
+    }
     if (int rc = bbme_get_geometry(ctx, &pw, &ph, nullptr, nullptr)) return rc;
     const int16_t *cells = nullptr;
     if (int rc = bbme_cells_device(ctx, &cells)) return rc;

@@ -9,6 +9,9 @@
 // only enqueued; the host then collects round k - 1 (whose download has had a whole round to finish) and hands its grids
 // to the writer.  The two host waits -- "writer done with round k - 2" before the download of round k may overwrite that
 // staging buffer, "download of round k - 1 complete" before its files are submitted -- are on work at least one round old.
+// The wait for the writer is for THAT round's files only (r04): the writer is a pool, files of later rounds may still be
+// in flight, and finish in any order.  Frames live in a ring of pinned slots that a reader fills ahead of the loop: a
+// round's slots are handed back once its download has completed (its uploads lie before that on the same stream).
 #pragma once
 
 namespace bbme {
@@ -19,13 +22,15 @@ namespace bbme {
 //   void root_wait_downloaded(int b)    rank 0's stream waits (device side) for the last download that read receive buffer b
 //   void gather(int b)                  every rank's cell grid -> receive buffer b on rank 0, on the ranks' streams
 //   void record_gathered(int b)         event on rank 0's stream behind the gather
-//   void host_wait_writer(int k)        HOST wait: the writer has finished every file of round k (k < 0: nothing)
+//   void host_wait_writer(int k)        HOST wait: the writer has finished every file of round k -- and only those (k < 0: nothing)
+//   void release_frames(int k)          host: the frame slots of round k may be refilled (its uploads have completed)
 //   void download(int b)                copy stream: waits for record_gathered(b), copies receive buffer b -> host buffer b
 //   void record_downloaded(int b)       event on the copy stream behind the download
 //   void host_wait_downloaded(int b)    HOST wait for record_downloaded(b)
 //   void submit_files(int k, int b)     host: one writer job per pair of round k, reading host buffer b
-// `faults` (tests only): bit 0 leaves out the wait for the writer, bit 1 the wait for the download -- the mock must then catch
-// a file with another pair's data, which is what shows that the test can see a missing wait at all.
+// `faults` (tests only): bit 0 leaves out the wait for the writer, bit 1 the wait for the download, bit 2 hands a round's
+// frame slots back before its uploads have run -- the mock must then catch a file with another pair's data (or an upload
+// from a slot that was given away), which is what shows that the test can see a missing wait at all.
 template <class Backend>
 void run_sequence(Backend &be, int gpus, int n_pairs, unsigned faults = 0)
 {
@@ -46,15 +51,19 @@ void run_sequence(Backend &be, int gpus, int n_pairs, unsigned faults = 0)
         be.record_downloaded(b);
         if (k >= 1) {                                                 // collect the round before: it has had a round to finish
             if (!(faults & 2u)) be.host_wait_downloaded(b ^ 1);
+            if (!(faults & 4u)) be.release_frames(k - 1);             // (fault 4: handed back a round early, below)
             be.submit_files(k - 1, b ^ 1);
         }
+        if (faults & 4u) be.release_frames(k);
     }
     if (rounds >= 1) {
         const int b = (rounds - 1) & 1;
         be.host_wait_downloaded(b);
+        be.release_frames(rounds - 1);
         be.submit_files(rounds - 1, b);
     }
-    be.host_wait_writer(rounds - 1);
+    // every round's files: rounds up to rounds - 3 were waited for inside the loop
+    for (int k = rounds >= 2 ? rounds - 2 : 0; k < rounds; ++k) be.host_wait_writer(k);
 }
 
 }  // namespace bbme

@@ -78,12 +78,19 @@ def subsample_div4(flow_padded, pad_x, pad_y, out_width, out_height):
 
 class FlowWriter:
     """Flow::WriteFlowFile on a worker thread (bbme_flo_writer_*): submit() returns at once, the file is written while
-    the next pair is being estimated.  The array handed to submit() must stay alive and untouched until wait()."""
+    the next pair is being estimated.  The array handed to submit() must stay alive and untouched until a wait covers it.
+    workers > 1: a pool, one file per worker at a time (files then finish in any order); submit*() return the job's ticket
+    and wait(ticket) returns once every job up to it is on disk."""
 
-    def __init__(self):
+    def __init__(self, workers=1):
         self._w = C.c_void_p()
-        _capi.check(_capi.lib().bbme_flo_writer_create(C.byref(self._w)))
+        _capi.check(_capi.lib().bbme_flo_writer_create_pool(int(workers), C.byref(self._w)))
         self._keep = []
+
+    def _ticket(self):
+        t = C.c_ulonglong()
+        _capi.check(_capi.lib().bbme_flo_writer_ticket(self._w, C.byref(t)))
+        return t.value
 
     def submit(self, flow_padded, filename, pad_x=0, pad_y=0, width=None, height=None):
         """The (height, width) window at (pad_y, pad_x) of a C-contiguous float32 (H, W, 2) field (default: all of it)."""
@@ -97,6 +104,7 @@ class FlowWriter:
         self._keep.append(f)
         ptr = f.ctypes.data + 8 * (pad_y * f.shape[1] + pad_x)
         _capi.check(_capi.lib().bbme_flo_writer_submit(self._w, os.fsencode(filename), width, height, C.c_void_p(ptr), f.shape[1]))
+        return self._ticket()
 
     def submit_cells(self, cells, filename, pad_x=0, pad_y=0, width=None, height=None):
         """The same file from the compact result of MF.get_cells (int16 (rows, cols, 2), one (dx, dy) per 2x2 pixels of the
@@ -109,8 +117,13 @@ class FlowWriter:
         self._keep.append(c)
         _capi.check(_capi.lib().bbme_flo_writer_submit_cells(self._w, os.fsencode(filename), width, height,
                                                              C.c_void_p(c.ctypes.data), c.shape[0], c.shape[1], pad_x, pad_y))
+        return self._ticket()
 
-    def wait(self):
+    def wait(self, ticket=None):
+        """Every job submitted so far, or (ticket) every job up to that one; the arrays of later jobs stay referenced."""
+        if ticket is not None:
+            _capi.check(_capi.lib().bbme_flo_writer_wait_ticket(self._w, int(ticket)))
+            return
         try:
             _capi.check(_capi.lib().bbme_flo_writer_wait(self._w))
         finally:

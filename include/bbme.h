@@ -77,10 +77,20 @@ int bbme_flo_write(const char *filename, int width, int height, const float *dat
  * is synchronous): submit hands over `height` rows of `width` (u, v) pairs starting at `data`, consecutive rows
  * `pitch_pixels` pixels apart -- e.g. the unpadded window of the padded field bbme_get_flow_host left in pinned memory:
  * data = flow + 2 * (pad_y * padded_width + pad_x), pitch_pixels = padded_width (main_class.cpp:63-70) -- and returns at
- * once; files are written in submission order, byte for byte what bbme_flo_write produces.  The memory must stay
- * untouched until bbme_flo_writer_wait returns, which also reports the first I/O error since the last wait. */
+ * once; a writer with one worker writes the files in submission order, byte for byte what bbme_flo_write produces.  The
+ * memory must stay untouched until a wait that covers the job returns; waits also report the first I/O error since the
+ * last one.
+ * bbme_flo_writer_create_pool: `workers` threads, one file each at a time -- files are independent, and one 66 MB file is
+ * bound by the kernel's write path (three writers in flight write a 4K sequence twice as fast as
+ * one); files then finish in any order.  Every submitted job has a ticket, 1, 2, ... in submission order:
+ * bbme_flo_writer_ticket gives the last one handed out, bbme_flo_writer_wait_ticket returns once every job up to that
+ * ticket is on disk (bbme_flo_writer_wait: every job submitted so far) -- what a pipeline needs that re-uses a staging
+ * buffer round by round (csrc/seq_schedule.hpp: only round k - 2 has to be on disk before round k's download). */
 typedef struct bbme_flo_writer bbme_flo_writer;
 int bbme_flo_writer_create(bbme_flo_writer **out);
+int bbme_flo_writer_create_pool(int workers, bbme_flo_writer **out);
+int bbme_flo_writer_ticket(bbme_flo_writer *w, unsigned long long *ticket);
+int bbme_flo_writer_wait_ticket(bbme_flo_writer *w, unsigned long long ticket);
 int bbme_flo_writer_submit(bbme_flo_writer *w, const char *filename, int width, int height, const float *data,
                            int pitch_pixels);
 /* The same file from the compact result (bbme_get_cells_host: one int16 (dx, dy) pair per 2x2 pixels of the padded level-0
@@ -110,8 +120,13 @@ void bbme_free(void *p);
 
 /* Host tables of the search kernels, exposed for tests.  bbme_spiral_host: visiting order of
  * find_min_block_spiral (motion_framework.cpp:326-411), rank -> (dx, dy).  bbme_search_plan_host: the
- * work split of k_search_fast -- strip height per round and 64 tasks (g | dy0 << 8, 0xffffffff = idle
- * lane) per round; together the tasks must cover every (column group, candidate row) exactly once. */
+ * work split of k_search_fast -- per round a code rounds[] = S | kind << 8 and 64 tasks (0xffffffff = idle lane):
+ *   kind 0  strips: a lane takes column group g (candidate columns 4g .. 4g+3) and the S candidate rows from dy0;
+ *           task = g | dy0 << 8;
+ *   kind 1  the last candidate row of the tight plan (even ranges, block <= 16): the four lanes of a quad share one
+ *           (group, row), a quarter of the block's rows each; task = g | dy << 8 | part << 16, part = 0..3;
+ *   kind 2  the last candidate column of the tight plan (dx = +R), one candidate per lane; task = dy.
+ * Together the tasks cover every candidate of the (2R+1)^2 square exactly once (kind 1: once per part). */
 int bbme_spiral_host(int search_size, int block_size, int16_t *dx, int16_t *dy, int capacity, int *count);
 int bbme_search_plan_host(int range, int block_size, uint32_t *rounds, int rounds_capacity, int *nrounds,
                           uint32_t *tasks /* rounds_capacity * 64 */, int *groups, int *pitch_dw);
@@ -190,7 +205,11 @@ int bbme_set_relaxation(bbme_ctx *ctx, int enabled);
  * Without it the caller must have synchronised the producer itself. */
 int bbme_wait_for_stream(bbme_ctx *ctx, void *producer_stream);
 /* Direct access to the ctx-owned padded planes of a level (device pointers, pitch ==
- * level width) so a caller can fill or inspect them in place. */
+ * level width) so a caller can fill or inspect them in place.
+ * SINGLE-PAIR ENTRY POINTS.  The three plane calls below, bbme_calculate_mse_device, every bbme_stage_* call,
+ * bbme_sweep_stats, bbme_last_sweep_passes and bbme_gather_cells (bbme_rccl.h) address one pair: on a batched context
+ * (bbme_create_batch with pairs > 1) they return BBME_ERR_UNSUPPORTED instead of quietly working on pair 0.  A batch
+ * is fed with bbme_set_frames_{host,device}_pair and read with the *_pair getters. */
 int bbme_level_planes_device(bbme_ctx *ctx, int level, uint8_t **d_image1, uint8_t **d_image2);
 /* Upload ready-made padded planes of one level (fixtures taken after the pyramid). */
 int bbme_set_level_planes_host(bbme_ctx *ctx, int level, const uint8_t *image1, const uint8_t *image2);
@@ -229,7 +248,7 @@ int bbme_get_cells_host_pair(bbme_ctx *ctx, int pair, int16_t *cells);
  * about 1e-12 relative, not bit for bit.  Synchronises the ctx stream. */
 int bbme_calculate_mse_device(bbme_ctx *ctx, const float *d_gtruth, int gt_width, int gt_height, int scale, double *out);
 
-/* ---- single stages, for parity tests against the reference's private methods -------- */
+/* ---- single stages, for parity tests against the reference's private methods (single-pair contexts only) -------- */
 
 /* copyMVs (:828-843) + calcLevelBM (:226-244) of one level.  Leaves that level's MV
  * grid at block size block_size[level]. */

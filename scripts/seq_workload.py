@@ -27,7 +27,12 @@ from bench import WORKLOADS                                      # noqa: E402
 
 w, h, search, block, levels, _ = WORKLOADS[a.workload]
 ctxs = []
-frames = [bbme.synth_pair(w, h, 1030 + k, max_motion=24)[:2] for k in range(a.pairs)]
+import numpy as np                                               # noqa: E402
+frames = [bbme.synth_pair(w, h, 1030 + k, max_motion=24)[:2] for k in range(min(a.pairs, 8))]
+while len(frames) < a.pairs:       # deeper than 8: the same pairs rolled by a few pixels, as bench.py's sequence_deep leg does
+    k = len(frames)
+    sh = (3 * (k // 8), 5 * (k // 8))
+    frames.append(tuple(np.ascontiguousarray(np.roll(f, sh, (0, 1))) for f in frames[k % 8]))
 for i in range(0, a.pairs, a.batch):
     mf = bbme.MFBatch(frames[i:i + a.batch], [search] * levels, [block] * levels, levels)
     mf.set_speculation(bool(a.speculate))

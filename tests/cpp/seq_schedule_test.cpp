@@ -1,8 +1,11 @@
 // CPU test of the ordering logic of bbme_seq's round pipeline (csrc/seq_schedule.hpp): a mock backend in which every HIP
-// stream, the copy stream and the writer thread are queues executed in a RANDOM interleaving that honours only what the real
-// machinery guarantees -- order within a queue, event waits, the root's gather completing after every rank's contribution,
-// host waits.  Every file must end up holding its own pair's result.  With a wait left out on purpose (faults) some seed must
-// produce a wrong file: that is what shows the test can see a missing wait.
+// stream, the copy stream, every worker of the writer pool and the frame reader are queues executed in a RANDOM interleaving
+// that honours only what the real machinery guarantees -- order within a queue, event waits, the root's gather completing
+// after every rank's contribution, host waits.  The writer is a pool: a file goes to any worker, files finish in any order,
+// and host_wait_writer(k) waits for round k's files ONLY.  Frames sit in a ring of three rounds of slots that the reader
+// refills as soon as a slot is handed back; an upload copies whatever its slot holds when it RUNS.  Every file must end up
+// holding its own pair's result.  With a wait left out on purpose (faults) some seed must produce a wrong file: that is what
+// shows the test can see a missing wait.
 //   g++ -std=c++17 -O1 -I blockbasedmotionestimation_amd/csrc tests/cpp/seq_schedule_test.cpp -o seq_schedule_test && ./seq_schedule_test
 #include <cstdio>
 #include <cstdlib>
@@ -17,7 +20,9 @@ struct Mock {
     struct Op { std::function<bool()> ready; std::function<void()> run; };
     int gpus, n_pairs;
     std::mt19937 rng;
-    std::vector<std::deque<Op>> q;                 // [0, gpus): rank streams; gpus: copy stream; gpus + 1: writer thread
+    static constexpr int kWriters = 3;
+    std::vector<std::deque<Op>> q;                 // [0, gpus): rank streams; gpus: copy stream; gpus + 1 .. + kWriters: writer pool; last: frame reader
+    std::vector<int> slot;                         // the frame ring: pair held by each slot, -1 = free
     std::vector<int> frames, cells;                // per rank
     std::vector<int> recv[2], host[2];             // per buffer, per rank
     std::vector<int> files;                        // per pair
@@ -28,11 +33,16 @@ struct Mock {
     std::vector<int> writer_jobs_left;             // per round
     static int result_of(int pair) { return pair * 7 + 3; }
 
-    Mock(int g, int n, unsigned seed) : gpus(g), n_pairs(n), rng(seed), q(g + 2), frames(g, -1), cells(g, -1), files(n, -1)
+    Mock(int g, int n, unsigned seed) : gpus(g), n_pairs(n), rng(seed), q(g + 2 + kWriters), slot(3 * g, -1), frames(g, -1), cells(g, -1), files(n, -1)
     {
         for (auto &v : recv) v.assign(g, -1);
         for (auto &v : host) v.assign(g, -1);
         writer_jobs_left.assign((n + g - 1) / g + 1, 0);
+        // the reader: pair after pair into its slot, as soon as that slot is free
+        for (int p = 0; p < n; ++p) {
+            const int s = p % (int)slot.size();
+            q.back().push_back({[this, s] { return slot[s] < 0; }, [this, s, p] { slot[s] = p; }});
+        }
     }
     bool step()                                     // run the head of a random runnable queue
     {
@@ -51,7 +61,24 @@ struct Mock {
     static bool always() { return true; }
     int new_ticket() { ticket_done.push_back(0); return (int)ticket_done.size() - 1; }
 
-    void upload(int r, int pair) { push(r, always, [this, r, pair] { frames[r] = pair; }); }
+    void upload(int r, int pair)
+    {
+        const int s = pair % (int)slot.size();
+        while (slot[s] != pair) {                                           // the host waits for the reader, which runs on its own:
+            auto &rq = q.back();                                            // the device need not make progress meanwhile
+            if (!rq.empty() && rq.front().ready()) { Op op = rq.front(); rq.pop_front(); op.run(); }
+            else if (!step()) { fprintf(stderr, "deadlock waiting for the frame reader\n"); exit(3); }
+        }
+        push(r, always, [this, r, s] { frames[r] = slot[s]; });              // copies what the slot holds when the copy RUNS
+    }
+    void release_frames(int k)
+    {
+        for (int r = 0; r < gpus; ++r) {
+            const int p = k * gpus + r;
+            if (p < n_pairs && slot[p % (int)slot.size()] == p) slot[p % (int)slot.size()] = -1;
+        }
+        pump();
+    }
     void estimate(int r) { push(r, always, [this, r] { cells[r] = result_of(frames[r]); }); }
     void root_wait_downloaded(int b)
     {
@@ -71,7 +98,7 @@ struct Mock {
     void host_wait_writer(int k)
     {
         if (k < 0) return;
-        while (writer_jobs_left[k] > 0 || !q[gpus + 1].empty())            // files are written in submission order
+        while (writer_jobs_left[k] > 0)                                     // round k's files, nothing else
             if (!step()) { fprintf(stderr, "deadlock waiting for the writer\n"); exit(3); }
     }
     void download(int b)
@@ -92,7 +119,8 @@ struct Mock {
             const int p = k * gpus + r;
             if (p >= n_pairs) continue;
             ++writer_jobs_left[k];
-            push(gpus + 1, always, [this, k, b, r, p] { files[p] = host[b][r]; --writer_jobs_left[k]; });   // reads the buffer when it RUNS
+            push(gpus + 1 + (int)(rng() % kWriters), always,
+                 [this, k, b, r, p] { files[p] = host[b][r]; --writer_jobs_left[k]; });                     // reads the buffer when it RUNS
         }
     }
     void drain() { while (step()) {} }
@@ -117,7 +145,7 @@ int main()
                 if (m.wrong()) { printf("FAIL: %d GPUs, %d pairs, seed %u: %d wrong files\n", gpus, n_pairs, seed, m.wrong()); ++failures; }
             }
     // a wait left out must be visible for some interleaving
-    for (unsigned fault : {1u, 2u}) {
+    for (unsigned fault : {1u, 2u, 4u}) {
         int caught = 0;
         for (unsigned seed = 0; seed < 400 && !caught; ++seed) {
             Mock m(2, 40, seed);

@@ -585,6 +585,67 @@ def test_batched_context_matches_the_oracle_pair_by_pair(bbme, oracle, w, h, sea
         assert np.array_equal(got[p], exp[p]), "pair %d (device frames)" % p
 
 
+@pytest.mark.parametrize("variant", ["generic_search", "raster", "block4", "block64"])
+def test_batched_context_with_the_generic_search_kernels(bbme, oracle, monkeypatch, variant):
+    """The pair as blockIdx.y of k_search_generic (block 4 and 64, the raster find_min_block variant, and BBME_GENERIC_SEARCH=1
+    on block sizes that normally take the strip kernel): every pair of a batched context against the oracle."""
+    if variant == "block4":
+        w, h, ss, bs = 200, 136, [12, 12], [4, 4]
+    elif variant == "block64":
+        w, h, ss, bs = 512, 384, [80, 80], [64, 64]
+    else:
+        w, h, ss, bs = 296, 200, [30, 40], [16, 8]
+    if variant == "generic_search":
+        monkeypatch.setenv("BBME_GENERIC_SEARCH", "1")
+    pairs = [bbme.synth_pair(w, h, 5300 + i, max_motion=5 + i)[:2] for i in range(3)]
+    mb = bbme.MFBatch(pairs, ss, bs, len(bs))
+    monkeypatch.delenv("BBME_GENERIC_SEARCH", raising=False)
+    mb.set_search_mode(variant == "raster")
+    got = mb.calcMotionBlockMatching()
+    mb.close()
+    for p, (f1, f2) in enumerate(pairs):
+        omf = oracle.OracleMF(f1, f2, ss, bs)
+        omf.set_raster_search(variant == "raster")
+        exp = omf.calc_motion_block_matching()
+        omf.close()
+        assert np.array_equal(got[p], exp), "pair %d (%s)" % (p, variant)
+
+
+def test_batched_context_refuses_single_pair_calls_and_wrong_tensors(bbme):
+    """The stage calls, the plane injection, the sweep counters and the device-side EPE address one pair: a batched context
+    refuses them (BBME_ERR_UNSUPPORTED) instead of working on pair 0.  A device tensor of another shape than the context's
+    frames is refused before its pointer reaches the padding kernel, and the inherited setters address pair 0."""
+    import torch
+    from blockbasedmotionestimation_amd import _capi
+    w, h = 200, 136
+    pairs = [bbme.synth_pair(w, h, 5400 + i, max_motion=4)[:2] for i in range(2)]
+    mb = bbme.MFBatch(pairs, [30, 30], [16, 16], 2)
+    for call in (lambda: mb.stage_search(1), lambda: mb.stage_regularize(1, 16, 1), lambda: mb.stage_get_mvs(1, 16),
+                 lambda: mb.stage_expand(), lambda: mb.sweep_stats(), lambda: mb.last_sweep_passes(),
+                 lambda: mb.set_level_planes(0, *mb.get_level_planes(0)),
+                 lambda: mb.calculate_mse_device(torch.zeros((h, w, 2), dtype=torch.float32, device="cuda"), 1)):
+        with pytest.raises(_capi.BbmeError) as err:
+            call()
+        assert err.value.status == _capi.ERR_UNSUPPORTED, err.value.message
+    good = torch.from_numpy(pairs[0][0]).cuda()
+    for bad in (torch.zeros((h - 8, w), dtype=torch.uint8, device="cuda"), torch.zeros((h, w), dtype=torch.int8, device="cuda"),
+                torch.zeros((1, h, w), dtype=torch.uint8, device="cuda")):
+        with pytest.raises(_capi.BbmeError) as err:
+            mb.set_pair_device(1, good, bad)
+        assert err.value.status == _capi.ERR_INVALID
+    with pytest.raises(_capi.BbmeError):
+        mb.set_pair_device(2, good, good)
+    ref = mb.calcMotionBlockMatching()
+    # the inherited entry points without a pair index address pair 0 and keep the bookkeeping intact
+    mb.set_frames_device(torch.from_numpy(pairs[1][0]).cuda(), torch.from_numpy(pairs[1][1]).cuda())
+    mb.set_pair_device(1, torch.from_numpy(pairs[0][0]).cuda(), torch.from_numpy(pairs[0][1]).cuda())
+    swapped = mb.calcMotionBlockMatching()
+    assert np.array_equal(swapped[0], ref[1]) and np.array_equal(swapped[1], ref[0])
+    mb.set_frames(*pairs[0])
+    assert np.array_equal(mb.calcMotionBlockMatching()[0], ref[0])
+    mb.close()
+
+
 def test_deep_batches_match_the_oracle(bbme, oracle):
     """The largest batch a context takes (BBME_MAX_BATCH = 64 pairs behind every launch; bench.py's `sequence_deep` legs) and
     two deep contexts side by side on their own streams: every pair's field must be the oracle's.  Twelve distinct pairs and

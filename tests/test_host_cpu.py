@@ -193,6 +193,38 @@ def test_async_flow_writer(bbme, tmp_path):
     w.close()
 
 
+def test_flow_writer_pool_and_tickets(bbme, tmp_path):
+    """bbme_flo_writer_create_pool / _ticket / _wait_ticket: several workers, one file each at a time; tickets count the jobs in
+    submission order, wait(ticket) returns once every job up to it is on disk -- whatever the later ones are doing -- and a
+    plain wait() covers everything.  What the sequence driver's round pipeline stands on (csrc/seq_schedule.hpp)."""
+    rng = np.random.default_rng(3)
+    cells = rng.integers(-50, 50, (240, 320, 2), dtype=np.int16)
+    w = bbme.FlowWriter(workers=3)
+    tickets = [w.submit_cells(cells, str(tmp_path / ("%02d.flo" % i))) for i in range(12)]
+    assert tickets == list(range(1, 13))
+    w.wait(tickets[3])                                             # jobs 1..4 are complete files now
+    ref = None
+    for i in range(4):
+        data = (tmp_path / ("%02d.flo" % i)).read_bytes()
+        assert len(data) == 12 + 8 * 640 * 480
+        ref = ref or data
+        assert data == ref
+    w.wait(10 ** 9)                                                # a ticket beyond the last one = everything submitted
+    w.wait()
+    assert all((tmp_path / ("%02d.flo" % i)).read_bytes() == ref for i in range(12))
+    # an I/O error of any worker surfaces at the next wait, and the pool stays usable
+    w.submit_cells(cells, str(tmp_path / "no_such_dir" / "x.flo"))
+    with pytest.raises(bbme.BbmeError) as e:
+        w.wait()
+    assert e.value.status == -6
+    t = w.submit_cells(cells, str(tmp_path / "again.flo"))
+    w.wait(t)
+    assert (tmp_path / "again.flo").read_bytes() == ref
+    w.close()
+    with pytest.raises(bbme.BbmeError):
+        bbme.FlowWriter(workers=0)
+
+
 @pytest.mark.parametrize("pads", [(0, 0), (4, 6), (3, 5), (1, 0)])
 @pytest.mark.parametrize("threads", ["1", "3"])
 def test_async_flow_writer_from_cells(bbme, tmp_path, monkeypatch, pads, threads):
