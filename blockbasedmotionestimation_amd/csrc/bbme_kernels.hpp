@@ -1233,7 +1233,7 @@ __device__ __forceinline__ uint32_t lane_sad(const RegArgs &a, int bx, int by, i
 
 // Second half: lane k16 of the group holds candidate k16's MV `mv`; every lane of the group returns the winner.
 // MEMO: `memo` is what the lane's slot held (slot k16; lanes 9..15 shadow slot 0) and `slot` where it lives.
-template <int BS, bool MEMO = false, bool COHERENT = false, bool GROUP = (COHERENT || BS >= 32)>
+template <int BS, bool MEMO = false, bool COHERENT = false, bool GROUP = ((COHERENT && BS >= 16) || BS >= 32)>
 __device__ __forceinline__ mv_t lanes_score(const RegArgs &a, int r, int c, int k16, bool present, mv_t mv,
                                             PhaseProf *prof = nullptr, uint2 memo = make_uint2(0, 0),
                                             uint32_t slot = 0, MemoStats *stats = nullptr)
@@ -1256,7 +1256,8 @@ __device__ __forceinline__ mv_t lanes_score(const RegArgs &a, int r, int c, int 
         if (stats) { stats->lookups += (uint32_t)__popcll(__ballot(inside)); stats->misses += (uint32_t)__popcll(nball); }
         if (nball) {
             if constexpr (GROUP) sad = group_sads<BS>(a, bx, by, k16, need, mv, sad, stats);
-            else if (need) sad = lane_sad<BS>(a, bx, by, x2, y2);           // pass 1 at b <= 16: any number of different vectors in one trip
+            else if (need) sad = lane_sad<BS>(a, bx, by, x2, y2);           // pass 1 at b <= 16, and b = 8 everywhere: the lanes in need walk
+                                                                            // their own rows -- any number of different vectors in one trip
         }
         // the slot now describes this lane's candidate (or nothing, if it has no SAD); written only when that is news
         const uint32_t nmv = inside ? mv : kMemoNoMv, nsad = inside ? sad : 0u;

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -136,10 +137,12 @@ struct HipBackend {
     std::vector<ncclComm_t> comms;
     std::vector<hipStream_t> stream;               // the contexts' streams
     hipStream_t copy_stream = nullptr;             // GPU 0: downloads beside the next round's estimates
-    int32_t *d_recv[2] = {nullptr, nullptr};
-    int32_t *host[2] = {nullptr, nullptr};         // pinned
-    hipEvent_t ev_gathered[2] = {nullptr, nullptr}, ev_downloaded[2] = {nullptr, nullptr};
-    bool downloaded_once[2] = {false, false};
+    // receive (HBM) and staging (pinned host) buffers of a round's gathered cell grids: a ring of `nbuf`, deep enough to keep
+    // every writer busy (a round's files stay in its staging buffer until they are written)
+    int nbuf = 2;
+    std::vector<int32_t *> d_recv, host;
+    std::vector<hipEvent_t> ev_gathered, ev_downloaded;
+    std::vector<char> downloaded_once;
     bbme_flo_writer *writer = nullptr;              // a pool: one file per worker at a time
     std::vector<unsigned long long> round_ticket;   // per round: the ticket of its last file
     std::string out_dir;
@@ -269,6 +272,9 @@ int main(int argc, char **argv)
     be.stream.assign(gpus, nullptr);
     for (int r = 0; r < gpus; ++r) {
         BBME_OKAY(bbme_create(&params, w, h, r, &be.ctx[r]));
+        // no speculative search: its graph has a forked branch, and a second stream (the copy stream here) waiting for an event
+        // behind such a graph costs the next replay 0.7 ms -- more than the speculation gains
+        if (!getenv("BBME_SPECULATE")) BBME_OKAY(bbme_set_speculation(be.ctx[r], 0));
         void *s = nullptr;
         BBME_OKAY(bbme_get_stream(be.ctx[r], &s));
         be.stream[r] = static_cast<hipStream_t>(s);
@@ -277,7 +283,12 @@ int main(int argc, char **argv)
     be.words = (size_t)(be.pw / 2) * (be.ph / 2);
     HIP_OK(hipSetDevice(0));
     HIP_OK(hipStreamCreateWithFlags(&be.copy_stream, hipStreamNonBlocking));
-    for (int b = 0; b < 2; ++b) {
+    // one round holds `gpus` files: enough rounds in the ring for every writer to have a file, plus the round being filled
+    be.nbuf = std::max(2, (writers + gpus - 1) / gpus + 1);
+    be.d_recv.assign(be.nbuf, nullptr); be.host.assign(be.nbuf, nullptr);
+    be.ev_gathered.assign(be.nbuf, nullptr); be.ev_downloaded.assign(be.nbuf, nullptr);
+    be.downloaded_once.assign(be.nbuf, 0);
+    for (int b = 0; b < be.nbuf; ++b) {
         HIP_OK(hipMalloc(&be.d_recv[b], be.words * gpus * sizeof(int32_t)));
         // pinned staging for the writer: the gathered cell grids of a round (1/16 of the dense fields); the writer expands them
         // while it writes (bbme_flo_writer_submit_cells)
@@ -288,11 +299,11 @@ int main(int argc, char **argv)
     BBME_OKAY(bbme_flo_writer_create_pool(writers, &be.writer));
 
     const auto t0 = std::chrono::steady_clock::now();
-    bbme::run_sequence(be, gpus, n_pairs);
+    bbme::run_sequence(be, gpus, n_pairs, 0, be.nbuf);
     for (int r = 0; r < gpus; ++r) BBME_OKAY(bbme_synchronize(be.ctx[r]));       // also refuses a field that did not converge
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    printf("%d pairs of %dx%d on %d GPU(s), %d writer(s): %.3f s (%.2f ms per pair, files included)\n", n_pairs, w, h, gpus, writers, secs,
-           secs / n_pairs * 1e3);
+    printf("%d pairs of %dx%d on %d GPU(s), %d writer(s), %d staging buffers: %.3f s (%.2f ms per pair, files included)\n", n_pairs, w, h, gpus,
+           writers, be.nbuf, secs, secs / n_pairs * 1e3);
     // per-round phases on GPU 0 (device time between stamps; the download runs on the copy stream beside the next round)
     const size_t rounds = be.t_gather.size();
     for (size_t k = 0; k < rounds && k < be.t_start.size(); ++k) {
@@ -310,7 +321,7 @@ int main(int argc, char **argv)
         for (hipEvent_t e : *v) (void)hipEventDestroy(e);
     bbme_flo_writer_destroy(be.writer);
     ring.finish();
-    for (int b = 0; b < 2; ++b) { (void)hipHostFree(be.host[b]); (void)hipFree(be.d_recv[b]); }
+    for (int b = 0; b < be.nbuf; ++b) { (void)hipHostFree(be.host[b]); (void)hipFree(be.d_recv[b]); }
     for (int r = 0; r < gpus; ++r) { bbme_destroy(be.ctx[r]); ncclCommDestroy(be.comms[r]); }
     return 0;
 }

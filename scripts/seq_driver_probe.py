@@ -19,12 +19,12 @@ with tempfile.TemporaryDirectory(dir="/tmp") as d:
             with open(path, "wb") as fh:
                 fh.write(b"P5\n3840 2160\n255\n" + f.tobytes())
             files.append(path)
-    for env in ({}, {"BBME_SPECULATE": "0"}):
-        out = os.path.join(d, "out_%s" % ("spec" if not env else "plain"))
+    for env, writers in (({}, 1), ({}, 3), ({}, 6), ({"BBME_SPECULATE": "0"}, 3)):
+        out = os.path.join(d, "out_%s_%d" % ("spec" if not env else "plain", writers))
         os.makedirs(out)
         e = dict(os.environ, **env)
         r = subprocess.run([os.path.join(ROOT, "blockbasedmotionestimation_amd", "bbme_seq"), "--gpus", "1", "--levels", "4", "--block", "16",
-                            "--search", "80", "--out", out] + files, env=e, capture_output=True, text=True, timeout=600)
-        print("== %s rc=%d" % (env or "default", r.returncode))
+                            "--search", "80", "--writers", str(writers), "--out", out] + files, env=e, capture_output=True, text=True, timeout=600)
+        print("== %s, %d writer(s): rc=%d" % (env or "default", writers, r.returncode))
         print(r.stdout[-3000:])
         print(r.stderr[-500:])

@@ -19,15 +19,17 @@
 struct Mock {
     struct Op { std::function<bool()> ready; std::function<void()> run; };
     int gpus, n_pairs;
+    int writer_lag = 0;                            // of 16 steps that could go to a writer worker, this many go elsewhere (a slow disk)
     std::mt19937 rng;
     static constexpr int kWriters = 3;
     std::vector<std::deque<Op>> q;                 // [0, gpus): rank streams; gpus: copy stream; gpus + 1 .. + kWriters: writer pool; last: frame reader
     std::vector<int> slot;                         // the frame ring: pair held by each slot, -1 = free
     std::vector<int> frames, cells;                // per rank
-    std::vector<int> recv[2], host[2];             // per buffer, per rank
+    static constexpr int kMaxBuf = 5;
+    std::vector<int> recv[kMaxBuf], host[kMaxBuf]; // per buffer, per rank
     std::vector<int> files;                        // per pair
     std::vector<char> ticket_done;                 // events: one ticket per record call
-    int gathered_ticket[2] = {-1, -1}, downloaded_ticket[2] = {-1, -1};
+    int gathered_ticket[kMaxBuf] = {-1, -1, -1, -1, -1}, downloaded_ticket[kMaxBuf] = {-1, -1, -1, -1, -1};
     std::vector<std::vector<int>> inflight;        // per gather: what every rank contributed
     std::vector<int> arrived;
     std::vector<int> writer_jobs_left;             // per round
@@ -50,7 +52,12 @@ struct Mock {
         for (int i = 0; i < (int)q.size(); ++i)
             if (!q[i].empty() && q[i].front().ready()) runnable.push_back(i);
         if (runnable.empty()) return false;
-        const int i = runnable[rng() % runnable.size()];
+        int i = runnable[rng() % runnable.size()];
+        if (writer_lag && i > gpus && i <= gpus + kWriters && (int)(rng() % 16) < writer_lag) {
+            std::vector<int> others;
+            for (int j : runnable) if (j <= gpus || j > gpus + kWriters) others.push_back(j);
+            if (!others.empty()) i = others[rng() % others.size()];
+        }
         Op op = q[i].front();
         q[i].pop_front();
         op.run();
@@ -136,25 +143,29 @@ int main()
 {
     int failures = 0;
     // the pipeline as shipped: every file right, whatever the interleaving
-    for (int gpus : {1, 2, 3, 8})
-        for (int n_pairs : {1, 2, 5, 8, 17, 40})
-            for (unsigned seed = 0; seed < 200; ++seed) {
-                Mock m(gpus, n_pairs, seed * 7919u + gpus * 31u + n_pairs);
-                bbme::run_sequence(m, gpus, n_pairs);
+    for (int nbuf : {2, 3, 5})
+        for (int gpus : {1, 2, 3, 8})
+            for (int n_pairs : {1, 2, 5, 8, 17, 40})
+                for (unsigned seed = 0; seed < 100; ++seed) {
+                    Mock m(gpus, n_pairs, seed * 7919u + gpus * 31u + n_pairs + nbuf * 1000003u);
+                    m.writer_lag = seed % 3 == 0 ? 15 : 0;                  // every third run with writers that fall far behind
+                    bbme::run_sequence(m, gpus, n_pairs, 0, nbuf);
+                    m.drain();
+                    if (m.wrong()) { printf("FAIL: %d buffers, %d GPUs, %d pairs, seed %u: %d wrong files\n", nbuf, gpus, n_pairs, seed, m.wrong()); ++failures; }
+                }
+    // a wait left out must be visible for some interleaving, whatever the depth of the ring
+    for (int nbuf : {2, 4})
+        for (unsigned fault : {1u, 2u, 4u}) {
+            int caught = 0;
+            for (unsigned seed = 0; seed < 600 && !caught; ++seed) {
+                Mock m(2, 40, seed);
+                m.writer_lag = fault == 1u ? 15 : 0;                        // a missing writer wait only shows when the writers are behind
+                bbme::run_sequence(m, 2, 40, fault, nbuf);
                 m.drain();
-                if (m.wrong()) { printf("FAIL: %d GPUs, %d pairs, seed %u: %d wrong files\n", gpus, n_pairs, seed, m.wrong()); ++failures; }
+                caught += m.wrong() != 0;
             }
-    // a wait left out must be visible for some interleaving
-    for (unsigned fault : {1u, 2u, 4u}) {
-        int caught = 0;
-        for (unsigned seed = 0; seed < 400 && !caught; ++seed) {
-            Mock m(2, 40, seed);
-            bbme::run_sequence(m, 2, 40, fault);
-            m.drain();
-            caught += m.wrong() != 0;
+            if (!caught) { printf("FAIL: the mock never noticed fault %u with %d buffers\n", fault, nbuf); ++failures; }
         }
-        if (!caught) { printf("FAIL: the mock never noticed fault %u\n", fault); ++failures; }
-    }
     if (failures) return 1;
     printf("seq_schedule ok\n");
     return 0;
