@@ -254,6 +254,19 @@ int launch_search_fast(bbme_ctx *c, int level, int mode, hipStream_t stream, siz
         a.mode = kSearchPlain;
         hipLaunchKernelGGL(k_fixup_list, dim3((nblocks + 255) / 256, P), dim3(256), 0, stream, a, L.block, L.fix_count, L.fix_list);
         const int lgrid = std::max(64, nblocks / 4);
+        // two waves per listed block where the 128-lane plan pays (r04): the list is one generation of waves (~5 000 blocks on
+        // 1 024 SIMDs at level 0), and halves balance it better than wholes -- 25.4 k SIMD-cycles per block against the 19.2 k
+        // of the plain level-0 launch; 1.569 -> 1.556 ms per cfg3 pair
+        static const bool list_split = !getenv("BBME_LIST_SPLIT") || atoi(getenv("BBME_LIST_SPLIT")) != 0;
+        if (list_split && L.tasks2 && (L.split_pays || c->split_forced) && c->split_blocks > 0) {
+            a.tasks = L.tasks2; a.rounds = L.rounds2; a.nrounds = L.nrounds2; a.lane_ranks = L.lane_ranks2;
+            a.stage_rpp = 128u / ((uint32_t)(L.fast_pitch_dw + 3) / 4);
+            if (L.block == 16) hipLaunchKernelGGL((k_search_list<16, 2>), dim3(lgrid, P), dim3(128), lds, stream, a, L.fix_count, L.fix_list);
+            else if (L.block == 32) hipLaunchKernelGGL((k_search_list<32, 2>), dim3(lgrid, P), dim3(128), lds, stream, a, L.fix_count, L.fix_list);
+            else hipLaunchKernelGGL((k_search_list<8, 2>), dim3(lgrid, P), dim3(128), lds, stream, a, L.fix_count, L.fix_list);
+            HIP_TRY(hipGetLastError());
+            return BBME_OK;
+        }
         if (L.block == 16) hipLaunchKernelGGL(k_search_list<16>, dim3(lgrid, P), dim3(64), lds, stream, a, L.fix_count, L.fix_list);
         else if (L.block == 32) hipLaunchKernelGGL(k_search_list<32>, dim3(lgrid, P), dim3(64), lds, stream, a, L.fix_count, L.fix_list);
         else hipLaunchKernelGGL(k_search_list<8>, dim3(lgrid, P), dim3(64), lds, stream, a, L.fix_count, L.fix_list);

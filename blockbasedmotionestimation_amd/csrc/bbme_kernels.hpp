@@ -729,8 +729,8 @@ __global__ __launch_bounds__(256) void k_fixup_list(FastSearchArgs a, int block,
 
 // (five waves per SIMD, 96 registers: a fix-up list of ~5 000 blocks at 4K then fits the chip's 5 120 wave slots in ONE generation instead
 // of a full one and a nearly empty one -- 64 -> 4x us at level 0)
-template <int B>
-__global__ __launch_bounds__(64, (B <= 16 ? 5 : 1)) void k_search_list(FastSearchArgs a, const uint32_t *count, const uint32_t *list)
+template <int B, int W = 1>
+__global__ __launch_bounds__(64 * W, (W == 1 && B <= 16 ? 5 : 1)) void k_search_list(FastSearchArgs a, const uint32_t *count, const uint32_t *list)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     shift_pair(a, blockIdx.y);
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(64, (B <= 16 ? 5 : 1)) void k_search_list(FastSearc
         const uint32_t brow = block_row(a, bid);
         mv_t m;
         (void)search_prediction(a, (int)brow * B, (int)(bid - brow * (uint32_t)a.cols) * B, bid, m);   // a.mode == kSearchPlain
-        search_block_fast<B>(a, bid, m, smem);
+        search_block_fast<B, W>(a, bid, m, smem);
         __syncthreads();                                                   // the window in LDS is re-used
     }
 }
