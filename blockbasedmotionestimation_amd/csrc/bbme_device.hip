@@ -110,7 +110,13 @@ struct bbme_ctx {
     bool speculate = true;                        // overlap every level's search with the coarser level's late sweeps; BBME_SPECULATE
     hipStream_t side_stream = nullptr;            // the speculative searches
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    size_t spec_lds = 0;                          // LDS per workgroup of a speculative search launch (occupancy cap)
+    int spec_per_cu = 0;                          // BBME_SPEC_WGS_PER_CU; 0 = by the coarser level's block size (spec_lds_for)
+    // LDS per workgroup of a speculative search launch beside the late sweeps of `coarser_block`-sized level: the occupancy cap
+    size_t spec_lds_for(int coarser_block) const
+    {
+        const int per_cu = spec_per_cu > 0 ? spec_per_cu : (coarser_block >= 16 ? 6 : 24);
+        return ((size_t)(160 - 40) * 1024 / per_cu) / 256 * 256;
+    }
     double spec_min_absdiffs = 8e9;               // levels with less search work are not speculated; BBME_SPEC_MIN_GABS
     hipGraphExec_t graph_exec = nullptr;
     bool profiling = false;
@@ -502,7 +508,7 @@ int enqueue_pyramid(bbme_ctx *c, bool speculate)
             if (speculate && l > 0 && b == c->lv[l].block && b > 2 && worth_speculating(c, l - 1)) {
                 HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
                 HIP_TRY(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
-                if (int rc = launch_search(c, l - 1, kSearchSpeculative, c->side_stream, c->spec_lds)) return rc;
+                if (int rc = launch_search(c, l - 1, kSearchSpeculative, c->side_stream, c->spec_lds_for(c->lv[l].block))) return rc;
                 HIP_TRY(hipEventRecord(c->ev_join, c->side_stream));
                 speculated = true;
             }
@@ -609,9 +615,10 @@ int bbme_create_batch(const bbme_params *params, int width, int height, int devi
     {
         // a speculative search may keep at most this many of its (one-wave) workgroups on a CU: the rest of the CU's wave
         // slots, registers and LDS (40 KB) stay free for the regulariser kernels it runs beside
-        int per_cu = 6;                                  // (r04: 6-7 measured best once the solver lost its counter atomics; 5 and 8 are 2 % slower)
-        if (const char *e = getenv("BBME_SPEC_WGS_PER_CU")) per_cu = std::max(1, std::min(32, atoi(e)));
-        c->spec_lds = ((size_t)(160 - 40) * 1024 / per_cu) / 256 * 256;
+        // (r04, on the faster solver.  Behind a level of 16 x 16 blocks -- three late block sizes to hide the search behind -- 6-7 is
+        // best: cfg3 1.614 / 1.585 / 1.591 / 1.626 ms at 8 / 6 / 7 / 5.  Behind a level of 8 x 8 blocks the sweeps are over long
+        // before the search is, and any cap only delays it: cfg4 1.80 / 1.72 / 1.67 / 1.62 ms at 6 / 8 / 10 / 24 = uncapped.)
+        if (const char *e = getenv("BBME_SPEC_WGS_PER_CU")) c->spec_per_cu = std::max(1, std::min(32, atoi(e)));
         if (const char *e = getenv("BBME_SPEC_MIN_GABS")) c->spec_min_absdiffs = atof(e) * 1e9;
     }
     if (const char *e = getenv("BBME_GENERIC_SEARCH")) c->force_generic_search = atoi(e) != 0;
