@@ -112,9 +112,11 @@ struct bbme_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int spec_per_cu = 0;                          // BBME_SPEC_WGS_PER_CU; 0 = by the coarser level's block size (spec_lds_for)
     // LDS per workgroup of a speculative search launch beside the late sweeps of `coarser_block`-sized level: the occupancy cap
-    size_t spec_lds_for(int coarser_block) const
+    int spec_per_cu_l0 = 0;                       // second value of BBME_SPEC_WGS_PER_CU="other,level0": the level-0 launch's own cap
+    size_t spec_lds_for(int coarser_block, int level = 1) const
     {
-        const int per_cu = spec_per_cu > 0 ? spec_per_cu : (coarser_block >= 16 ? 6 : 24);
+        int per_cu = spec_per_cu > 0 ? spec_per_cu : (coarser_block >= 16 ? 6 : 24);
+        if (level == 0 && spec_per_cu_l0 > 0) per_cu = spec_per_cu_l0;
         return ((size_t)(160 - 40) * 1024 / per_cu) / 256 * 256;
     }
     double spec_min_absdiffs = 8e9;               // levels with less search work are not speculated; BBME_SPEC_MIN_GABS
@@ -260,11 +262,12 @@ int launch_search_fast(bbme_ctx *c, int level, int mode, hipStream_t stream, siz
         a.mode = kSearchPlain;
         hipLaunchKernelGGL(k_fixup_list, dim3((nblocks + 255) / 256, P), dim3(256), 0, stream, a, L.block, L.fix_count, L.fix_list);
         const int lgrid = std::max(64, nblocks / 4);
-        // two waves per listed block where the 128-lane plan pays (r04): the list is one generation of waves (~5 000 blocks on
-        // 1 024 SIMDs at level 0), and halves balance it better than wholes -- 25.4 k SIMD-cycles per block against the 19.2 k
-        // of the plain level-0 launch; 1.569 -> 1.556 ms per cfg3 pair
+        // two waves per listed block on the levels that are searched with two waves per block anyway (r04): the list is ONE
+        // generation of waves, and on a level of 8 160 blocks (~1 200 listed) halves fill the chip where wholes leave three SIMDs
+        // in four idle -- 30.4 -> 24.8 us.  Level 0 (~5 000 listed) stays with one wave per block: at two, the 123 registers of
+        // the 128-lane form allow four waves per SIMD, 10 000 halves are two and a half generations, 58.8 -> 65.8 us.
         static const bool list_split = !getenv("BBME_LIST_SPLIT") || atoi(getenv("BBME_LIST_SPLIT")) != 0;
-        if (list_split && L.tasks2 && (L.split_pays || c->split_forced) && c->split_blocks > 0) {
+        if (list_split && L.tasks2 && nblocks <= c->split_blocks && (L.split_pays || c->split_forced)) {
             a.tasks = L.tasks2; a.rounds = L.rounds2; a.nrounds = L.nrounds2; a.lane_ranks = L.lane_ranks2;
             a.stage_rpp = 128u / ((uint32_t)(L.fast_pitch_dw + 3) / 4);
             if (L.block == 16) hipLaunchKernelGGL((k_search_list<16, 2>), dim3(lgrid, P), dim3(128), lds, stream, a, L.fix_count, L.fix_list);
@@ -508,7 +511,7 @@ int enqueue_pyramid(bbme_ctx *c, bool speculate)
             if (speculate && l > 0 && b == c->lv[l].block && b > 2 && worth_speculating(c, l - 1)) {
                 HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
                 HIP_TRY(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
-                if (int rc = launch_search(c, l - 1, kSearchSpeculative, c->side_stream, c->spec_lds_for(c->lv[l].block))) return rc;
+                if (int rc = launch_search(c, l - 1, kSearchSpeculative, c->side_stream, c->spec_lds_for(c->lv[l].block, l - 1))) return rc;
                 HIP_TRY(hipEventRecord(c->ev_join, c->side_stream));
                 speculated = true;
             }
@@ -618,7 +621,10 @@ int bbme_create_batch(const bbme_params *params, int width, int height, int devi
         // (r04, on the faster solver.  Behind a level of 16 x 16 blocks -- three late block sizes to hide the search behind -- 6-7 is
         // best: cfg3 1.614 / 1.585 / 1.591 / 1.626 ms at 8 / 6 / 7 / 5.  Behind a level of 8 x 8 blocks the sweeps are over long
         // before the search is, and any cap only delays it: cfg4 1.80 / 1.72 / 1.67 / 1.62 ms at 6 / 8 / 10 / 24 = uncapped.)
-        if (const char *e = getenv("BBME_SPEC_WGS_PER_CU")) c->spec_per_cu = std::max(1, std::min(32, atoi(e)));
+        if (const char *e = getenv("BBME_SPEC_WGS_PER_CU")) {
+            c->spec_per_cu = std::max(1, std::min(32, atoi(e)));
+            if (const char *comma = strchr(e, ',')) c->spec_per_cu_l0 = std::max(1, std::min(32, atoi(comma + 1)));
+        }
         if (const char *e = getenv("BBME_SPEC_MIN_GABS")) c->spec_min_absdiffs = atof(e) * 1e9;
     }
     if (const char *e = getenv("BBME_GENERIC_SEARCH")) c->force_generic_search = atoi(e) != 0;
