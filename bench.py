@@ -61,8 +61,6 @@ def check_all_pairs(bbme, ctxs, frames, per, search, block, levels, device):
     """Every pair of every batched context against a context of its own on the same frames (the int16 2x2-cell grids: exactly
     the information of the dense field).  Outside every timed region."""
     mf, ok = None, True
-    if os.environ.get("BBME_BENCH_NO_PAIRCHECK"):
-        return None
     for i, (a1, a2) in enumerate(frames):
         if mf is None:
             mf = bbme.MF(a1, a2, per_level(search, levels), per_level(block, levels), levels, device=device, frames_on_device=True)
