@@ -950,7 +950,7 @@ def test_sad_memo_hits_and_misses(bbme, oracle, monkeypatch, b):
     # runs with and without forwarding)
     for env in ({}, {"BBME_MEMO": "0"}, {"BBME_MEMO_FORWARD": "1"}, {"BBME_SOLVE_WGS": "1", "BBME_SOLVE_WAVES": "1"},
                 {"BBME_WIDE_THRESHOLD": "4", "BBME_MEMO_FORWARD": "1"}):
-        env = dict(env, BBME_MEMO_MIN_B="8")
+        env = dict({"BBME_MEMO": "1", "BBME_MEMO_FORWARD": "0"}, **env, BBME_MEMO_MIN_B="8")   # whatever the suite runs under
         for k, val in env.items():
             monkeypatch.setenv(k, val)
         mf = bbme.MF(f1, f2, search, block, 1)
