@@ -348,8 +348,22 @@ void launch_sweep_t(RegArgs a, uint8_t *const flags[2], int relax_steps, int max
         }
         if (BS <= 16 && blocks <= lanes_max)               // (b >= 32: a lane would walk 32+ rows -- 13 against 6 us at b = 32)
             hipLaunchKernelGGL(k_reg_pass1_lanes<BS>, dim3((unsigned)((blocks * 16 + 255) / 256), P), dim3(256), 0, s, a);
-        else
+        else {
+            if constexpr (BS <= 4) {
+                // the large grids of small blocks in a BATCHED context: strips of four blocks per lane, the blocks that need their
+                // images listed per wave and worked off densely.  A third fewer vector instructions per pair -- which a batch,
+                // throughput-bound, turns into time (24 pairs as 4 x 6: 60.0 -> 62.3 Mblocks/s) -- in a quarter of the waves, each of
+                // which now walks its list pass after pass -- which a single pair, latency-bound, pays for (level 0, b = 4: 15.8 ->
+                // 53 us; 1.563 -> 1.657 ms per step).  BBME_PASS1_STRIP=0 / 1 forces it off / on.
+                static const int strip_env = getenv("BBME_PASS1_STRIP") ? atoi(getenv("BBME_PASS1_STRIP")) : -1;
+                const bool strip_form = strip_env < 0 ? P > 1 : strip_env != 0;
+                if (strip_form && a.cols % 4 == 0 && a.cols >= 12) {
+                    hipLaunchKernelGGL(k_reg_pass1_strip<BS>, dim3((unsigned)((blocks / 4 + 255) / 256), P), dim3(256), 0, s, a);
+                    return;
+                }
+            }
             hipLaunchKernelGGL(k_reg_pass1<BS>, dim3(grid1, P), dim3(256), 0, s, a);
+        }
     };
     if (jacobi) {
         // opt-in, NOT the reference's field: every block against the field as the previous sweep left it, and no more

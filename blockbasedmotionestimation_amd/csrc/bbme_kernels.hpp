@@ -1437,6 +1437,105 @@ __global__ __launch_bounds__(256) void k_reg_pass1(RegArgs a)
     }
 }
 
+// Pass 1 on the large grids of small blocks (b = 2, 4; hundreds of thousands to millions of blocks), r04.  Measured with the image
+// path switched off, 70 % of k_reg_pass1 there is the test "are the nine candidates equal?" -- three 12-byte loads, eight compares and a
+// 4-byte store per block, one block per lane (b = 2) or per four lanes (b = 4) -- and the rest is the evaluations of the few blocks that
+// fail it, run by whole waves for a handful of live lanes.  Here a lane tests a STRIP of four blocks of a row from a 3 x 6 window (six
+// loads for four blocks instead of twelve, one 16-byte store), and the blocks that need their images are not evaluated where they
+// were found: the wave lists them (ballots, no barrier) and works the list off densely, 64 / LPB blocks per pass -- blocks that need
+// their images come in clusters (motion boundaries), so one dense pass replaces what were several sparse ones.
+template <int BS>
+__global__ __launch_bounds__(256) void k_reg_pass1_strip(RegArgs a)
+{
+    constexpr int LPB = RegCfg<BS>::LPB;                       // 1 (b = 2) or 4 (b = 4): lanes per block on the image path
+    static_assert(BS == 2 || BS == 4, "small blocks");
+    __shared__ uint32_t s_list[4][256];                       // per wave: the blocks of its 64 strips that need their images
+    __builtin_amdgcn_s_setprio(2);
+    shift_pair(a, blockIdx.y);
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t < 16 && t != 5) a.counters[t] = 0;                  // as k_reg_pass1
+    const int lane = (int)(threadIdx.x & 63u);
+    uint32_t *list = s_list[threadIdx.x >> 6];
+    const uint32_t spr = (uint32_t)a.cols >> 2;                // strips per row (the host takes this form only when 4 | cols)
+    const uint32_t nstrips = spr * (uint32_t)a.rows;
+    const bool valid = t < nstrips;
+    const uint32_t ts = valid ? t : nstrips - 1;
+    const int r = (int)(ts / spr), c0 = (int)(ts - (uint32_t)r * spr) * 4;
+    const uint32_t cell0 = (uint32_t)r * (uint32_t)a.cols + (uint32_t)c0;
+    uint32_t need = valid ? 0xfu : 0u;                         // bit j: block c0 + j takes the image path (border strips: all four)
+    if (valid && r >= 1 && r + 1 < a.rows && c0 >= 4 && c0 + 4 < a.cols) {
+        mv_t own[4];
+        need = 0;
+        if (a.old_shift == 0) {
+            struct __attribute__((packed, aligned(1))) hex_t { uint32_t v[6]; };
+            const mv_t *p = a.old_grid + (size_t)(r - 1) * a.old_cols + (c0 - 1);
+            hex_t row[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) row[i] = *reinterpret_cast<const hex_t *>(p + (size_t)i * a.old_cols);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                own[j] = row[1].v[j + 1];
+                bool uniform = true;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) uniform &= row[i].v[j + d] == own[j];
+                if (!uniform) need |= 1u << j;
+            }
+        } else {
+            // the old grid is the parent grid: columns c0 - 1 .. c0 + 4 lie in parent columns c0 / 2 - 1 .. c0 / 2 + 2, rows r - 1 .. r + 1
+            // in parent rows (r - 1) >> 1 and that + 1
+            struct __attribute__((packed, aligned(1))) quad_t { uint32_t v[4]; };
+            const int pr0 = (r - 1) >> 1, pc0 = (c0 >> 1) - 1;
+            const mv_t *p = a.old_grid + (size_t)pr0 * a.old_cols + pc0;
+            const quad_t w0 = *reinterpret_cast<const quad_t *>(p), w1 = *reinterpret_cast<const quad_t *>(p + a.old_cols);
+            const bool mid_hi = !(r & 1);                                     // row r itself: parent row pr0 (r odd) or pr0 + 1 (r even)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // column c0 + k (c0 a multiple of 4) lies in parent column c0 / 2 + (k >> 1) = pc0 + 1 + (k >> 1); k = -1: pc0
+                own[j] = mid_hi ? w1.v[(j >> 1) + 1] : w0.v[(j >> 1) + 1];
+                bool uniform = true;
+#pragma unroll
+                for (int dc = -1; dc <= 1; ++dc) {
+                    const int k = j + dc, pc = k < 0 ? 0 : (k >> 1) + 1;
+                    uniform &= w0.v[pc] == own[j];                            // row r - 1: always parent row pr0
+                    uniform &= w1.v[pc] == own[j];                            // row r + 1: always parent row pr0 + 1
+                    // (row r is one of the two)
+                }
+                if (!uniform) need |= 1u << j;
+            }
+        }
+        // nine equal candidates: the block keeps its vector (:648-660); the others get theirs below, this is their old value meanwhile
+        struct __attribute__((aligned(16))) out_t { uint32_t v[4]; };
+        *reinterpret_cast<out_t *>(a.est + cell0) = out_t{{own[0], own[1], own[2], own[3]}};
+    }
+    // the wave's list of blocks for the image path: ranks from four ballots
+    uint32_t total = 0;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned long long m = __ballot((need >> j) & 1u);
+        if ((need >> j) & 1u) list[total + (uint32_t)__popcll(m & lt_mask)] = cell0 + (uint32_t)j;
+        total += (uint32_t)__popcll(m);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the wave's own LDS writes, before its own reads
+    constexpr int PER = 64 / LPB;                             // blocks per pass
+    const int sub = lane & (LPB - 1);
+    for (uint32_t base = 0; base < total; base += PER) {      // wave-uniform
+        const uint32_t idx = base + (uint32_t)(lane / LPB);
+        if (idx < total) {                                     // whole groups
+            const uint32_t cell = list[idx];
+            const int rr = (int)(cell / (uint32_t)a.cols), cc = (int)(cell - (uint32_t)rr * (uint32_t)a.cols);
+            const mv_t res = eval_block<BS, false, true>(a, rr, cc, sub, 0u);
+            if (sub == 0) {
+                const mv_t old = a.old_grid[(size_t)(rr >> a.old_shift) * a.old_cols + (cc >> a.old_shift)];
+                a.est[cell] = res;
+                if (a.flag_next && res != old) mark_dependants(a, a.flag_next, rr, cc);
+            }
+        }
+    }
+}
+
 // Relaxation over the marked blocks, the whole chip at once, before the solver.  The grid is cut into tiles of
 // T x T blocks, one workgroup each.  A workgroup keeps the estimates of its tile (+ the ring of neighbours it reads:
 // one column left and right, one row above) in LDS, evaluates the marked blocks of the tile, and when a block
