@@ -81,6 +81,8 @@ struct bbme_ctx {
     bool split_forced = false;                    // threshold given in the environment: split whatever the plans' lengths (tests)
     long long scan_fine_max = 140000;             // grids of at most this many blocks: scan segments of 4 flags (BBME_SCAN_FINE_MAX)
     long long pass1_lanes_max = 140000;           // grids of at most this many blocks: pass 1 in the chain form (BBME_PASS1_LANES_MAX)
+    bool list_split = true;                       // two waves per listed block in the fix-up search of small levels; BBME_LIST_SPLIT
+    int pass1_strip = -1;                         // the strip form of pass 1 at b <= 4 (k_reg_pass1_strip): -1 = batched contexts only; BBME_PASS1_STRIP
     int split_blocks = 10000;                     // levels of at most this many macroblocks: two waves per block (BBME_SEARCH_SPLIT_BLOCKS)
     int round_cap = 0;                            // > 0: test knob, the regulariser's waves give up after this many rounds
     uint32_t *own = nullptr;                      // ownership counters of the solver, one word per block
@@ -266,8 +268,7 @@ int launch_search_fast(bbme_ctx *c, int level, int mode, hipStream_t stream, siz
         // generation of waves, and on a level of 8 160 blocks (~1 200 listed) halves fill the chip where wholes leave three SIMDs
         // in four idle -- 30.4 -> 24.8 us.  Level 0 (~5 000 listed) stays with one wave per block: at two, the 123 registers of
         // the 128-lane form allow four waves per SIMD, 10 000 halves are two and a half generations, 58.8 -> 65.8 us.
-        static const bool list_split = !getenv("BBME_LIST_SPLIT") || atoi(getenv("BBME_LIST_SPLIT")) != 0;
-        if (list_split && L.tasks2 && nblocks <= c->split_blocks && (L.split_pays || c->split_forced)) {
+        if (c->list_split && L.tasks2 && nblocks <= c->split_blocks && (L.split_pays || c->split_forced)) {
             a.tasks = L.tasks2; a.rounds = L.rounds2; a.nrounds = L.nrounds2; a.lane_ranks = L.lane_ranks2;
             a.stage_rpp = 128u / ((uint32_t)(L.fast_pitch_dw + 3) / 4);
             if (L.block == 16) hipLaunchKernelGGL((k_search_list<16, 2>), dim3(lgrid, P), dim3(128), lds, stream, a, L.fix_count, L.fix_list);
@@ -328,7 +329,7 @@ int launch_search(bbme_ctx *c, int level, int mode = kSearchPlain, hipStream_t s
 
 template <int BS>
 void launch_sweep_t(RegArgs a, uint8_t *const flags[2], int relax_steps, int max_solve_wgs, int solve_waves, bool jacobi,
-                    long long lanes_max, long long fine_max, unsigned P, hipStream_t s)
+                    long long lanes_max, long long fine_max, int strip, unsigned P, hipStream_t s)
 {
     constexpr int LPB = RegCfg<BS>::LPB;
     const long long blocks = (long long)a.rows * a.cols;
@@ -355,8 +356,7 @@ void launch_sweep_t(RegArgs a, uint8_t *const flags[2], int relax_steps, int max
                 // throughput-bound, turns into time (24 pairs as 4 x 6: 60.0 -> 62.3 Mblocks/s) -- in a quarter of the waves, each of
                 // which now walks its list pass after pass -- which a single pair, latency-bound, pays for (level 0, b = 4: 15.8 ->
                 // 53 us; 1.563 -> 1.657 ms per step).  BBME_PASS1_STRIP=0 / 1 forces it off / on.
-                static const int strip_env = getenv("BBME_PASS1_STRIP") ? atoi(getenv("BBME_PASS1_STRIP")) : -1;
-                const bool strip_form = strip_env < 0 ? P > 1 : strip_env != 0;
+                const bool strip_form = strip < 0 ? P > 1 : strip != 0;
                 if (strip_form && a.cols % 4 == 0 && a.cols >= 12) {
                     hipLaunchKernelGGL(k_reg_pass1_strip<BS>, dim3((unsigned)((blocks / 4 + 255) / 256), P), dim3(256), 0, s, a);
                     return;
@@ -460,12 +460,12 @@ int launch_sweep(bbme_ctx *c, int level, int b, int mult, bool stats = false)
         steps = (c->relax && nblk >= min_blocks && b <= max_b) ? (mult == 1 ? s1 : s2) : 0;
     }
     switch (b) {
-    case 2:  launch_sweep_t<2>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, (unsigned)c->batch, c->stream); break;
-    case 4:  launch_sweep_t<4>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, (unsigned)c->batch, c->stream); break;
-    case 8:  launch_sweep_t<8>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, (unsigned)c->batch, c->stream); break;
-    case 16: launch_sweep_t<16>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, (unsigned)c->batch, c->stream); break;
-    case 32: launch_sweep_t<32>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, (unsigned)c->batch, c->stream); break;
-    case 64: launch_sweep_t<64>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, (unsigned)c->batch, c->stream); break;
+    case 2:  launch_sweep_t<2>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->pass1_strip, (unsigned)c->batch, c->stream); break;
+    case 4:  launch_sweep_t<4>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->pass1_strip, (unsigned)c->batch, c->stream); break;
+    case 8:  launch_sweep_t<8>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->pass1_strip, (unsigned)c->batch, c->stream); break;
+    case 16: launch_sweep_t<16>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->pass1_strip, (unsigned)c->batch, c->stream); break;
+    case 32: launch_sweep_t<32>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->pass1_strip, (unsigned)c->batch, c->stream); break;
+    case 64: launch_sweep_t<64>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->pass1_strip, (unsigned)c->batch, c->stream); break;
     default: return bbme::fail(BBME_ERR_UNSUPPORTED, "block size %d", b);
     }
     HIP_TRY(hipGetLastError());
@@ -626,6 +626,8 @@ int bbme_create_batch(const bbme_params *params, int width, int height, int devi
     if (pairs > 1) c->pass1_lanes_max = 40000;
     if (const char *e = getenv("BBME_PASS1_LANES_MAX")) c->pass1_lanes_max = atoll(e);
     if (const char *e = getenv("BBME_SCAN_FINE_MAX")) c->scan_fine_max = atoll(e);
+    if (const char *e = getenv("BBME_PASS1_STRIP")) c->pass1_strip = atoi(e) != 0 ? 1 : 0;
+    if (const char *e = getenv("BBME_LIST_SPLIT")) c->list_split = atoi(e) != 0;
     if (const char *e = getenv("BBME_SEARCH_SPLIT_BLOCKS")) { c->split_blocks = std::max(0, atoi(e)); c->split_forced = true; }
     if (const char *e = getenv("BBME_NO_GRAPH")) c->use_graph = atoi(e) == 0;
     if (const char *e = getenv("BBME_SPECULATE")) c->speculate = atoi(e) != 0;

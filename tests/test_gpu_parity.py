@@ -262,6 +262,26 @@ def test_stagewise_parity_with_a_one_wave_solver(bbme, oracle, monkeypatch):
     compare_stagewise(bbme, oracle, n1, n2, [40, 40], [8, 8])
 
 
+def test_stagewise_parity_with_the_strip_form_of_pass_1(bbme, oracle, monkeypatch):
+    """k_reg_pass1_strip (what batched contexts run pass 1 with on large grids of 2 x 2 and 4 x 4 blocks: four blocks per lane from a
+    3 x 6 window, the blocks that need their images listed per wave and evaluated densely), forced onto a single-pair context and onto
+    every grid: every intermediate MV grid against the oracle -- first sweeps (candidates from the parent grid) and second sweeps,
+    grids whose width is a multiple of four blocks and grids that fall back to the plain form, content with many and with few
+    non-uniform neighbourhoods."""
+    monkeypatch.setenv("BBME_PASS1_STRIP", "1")
+    monkeypatch.setenv("BBME_PASS1_LANES_MAX", "0")
+    f1, f2, _ = bbme.synth_pair(384, 256, 6161, max_motion=14)
+    compare_stagewise(bbme, oracle, f1, f2, [48, 48, 48], [16, 16, 16])
+    f1, f2, _ = bbme.synth_pair(216, 136, 6162, max_motion=6)          # b = 4: 54 columns (plain form), b = 2: 108 (strips)
+    compare_stagewise(bbme, oracle, f1, f2, [24, 24], [8, 8])
+    rng = np.random.default_rng(13)
+    n1 = rng.integers(0, 256, (128, 192), dtype=np.uint8)
+    n2 = rng.integers(0, 256, (128, 192), dtype=np.uint8)
+    compare_stagewise(bbme, oracle, n1, n2, [24, 24], [4, 4])         # unrelated frames: nearly every block takes the image path
+    z = np.zeros((96, 160), np.uint8)
+    compare_stagewise(bbme, oracle, z, z, [16, 16], [4, 4])           # flat: none does
+
+
 def test_stagewise_parity_with_relaxation_steps(bbme, oracle, monkeypatch):
     """Every intermediate MV grid with two relaxation launches forced into every sweep (k_reg_iter: the tile-resident
     local fixed point), on content with many changes per sweep and on every block size."""
