@@ -82,6 +82,7 @@ struct bbme_ctx {
     long long scan_fine_max = 140000;             // grids of at most this many blocks: scan segments of 4 flags (BBME_SCAN_FINE_MAX)
     long long pass1_lanes_max = 140000;           // grids of at most this many blocks: pass 1 in the chain form (BBME_PASS1_LANES_MAX)
     bool list_split = true;                       // two waves per listed block in the fix-up search of small levels; BBME_LIST_SPLIT
+    bool pass1_lazy = true;                       // pass 1 leaves its evaluations to a relaxation launch that follows it; BBME_PASS1_LAZY
     int pass1_strip = -1;                         // the strip form of pass 1 at b <= 4 (k_reg_pass1_strip): -1 = batched contexts only; BBME_PASS1_STRIP
     int split_blocks = 10000;                     // levels of at most this many macroblocks: two waves per block (BBME_SEARCH_SPLIT_BLOCKS)
     int round_cap = 0;                            // > 0: test knob, the regulariser's waves give up after this many rounds
@@ -329,7 +330,7 @@ int launch_search(bbme_ctx *c, int level, int mode = kSearchPlain, hipStream_t s
 
 template <int BS>
 void launch_sweep_t(RegArgs a, uint8_t *const flags[2], int relax_steps, int max_solve_wgs, int solve_waves, bool jacobi,
-                    long long lanes_max, long long fine_max, int strip, unsigned P, hipStream_t s)
+                    long long lanes_max, long long fine_max, int strip, bool lazy_ok, unsigned P, hipStream_t s)
 {
     constexpr int LPB = RegCfg<BS>::LPB;
     const long long blocks = (long long)a.rows * a.cols;
@@ -356,12 +357,17 @@ void launch_sweep_t(RegArgs a, uint8_t *const flags[2], int relax_steps, int max
                 // throughput-bound, turns into time (24 pairs as 4 x 6: 60.0 -> 62.3 Mblocks/s) -- in a quarter of the waves, each of
                 // which now walks its list pass after pass -- which a single pair, latency-bound, pays for (level 0, b = 4: 15.8 ->
                 // 53 us; 1.563 -> 1.657 ms per step).  BBME_PASS1_STRIP=0 / 1 forces it off / on.
-                const bool strip_form = strip < 0 ? P > 1 : strip != 0;
+                // ... and, for any context, the sweeps with a relaxation launch behind pass 1: the strip test alone (level 0: 5.1 us at
+                // b = 4, 6.5 at b = 2, against 15.5 / 18.4 for the whole of k_reg_pass1), the blocks that need their images flagged for
+                // the relaxation's first round (RegArgs::lazy)
+                a.lazy = (lazy_ok && relax_steps > 0 && a.flag_next != nullptr) ? 1 : 0;
+                const bool strip_form = a.lazy || (strip < 0 ? P > 1 : strip != 0);
                 if (strip_form && a.cols % 4 == 0 && a.cols >= 12) {
                     hipLaunchKernelGGL(k_reg_pass1_strip<BS>, dim3((unsigned)((blocks / 4 + 255) / 256), P), dim3(256), 0, s, a);
                     return;
                 }
             }
+            a.lazy = 0;
             hipLaunchKernelGGL(k_reg_pass1<BS>, dim3(grid1, P), dim3(256), 0, s, a);
         }
     };
@@ -460,12 +466,12 @@ int launch_sweep(bbme_ctx *c, int level, int b, int mult, bool stats = false)
         steps = (c->relax && nblk >= min_blocks && b <= max_b) ? (mult == 1 ? s1 : s2) : 0;
     }
     switch (b) {
-    case 2:  launch_sweep_t<2>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->pass1_strip, (unsigned)c->batch, c->stream); break;
-    case 4:  launch_sweep_t<4>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->pass1_strip, (unsigned)c->batch, c->stream); break;
-    case 8:  launch_sweep_t<8>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->pass1_strip, (unsigned)c->batch, c->stream); break;
-    case 16: launch_sweep_t<16>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->pass1_strip, (unsigned)c->batch, c->stream); break;
-    case 32: launch_sweep_t<32>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->pass1_strip, (unsigned)c->batch, c->stream); break;
-    case 64: launch_sweep_t<64>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->pass1_strip, (unsigned)c->batch, c->stream); break;
+    case 2:  launch_sweep_t<2>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->pass1_strip, c->pass1_lazy, (unsigned)c->batch, c->stream); break;
+    case 4:  launch_sweep_t<4>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->pass1_strip, c->pass1_lazy, (unsigned)c->batch, c->stream); break;
+    case 8:  launch_sweep_t<8>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->pass1_strip, c->pass1_lazy, (unsigned)c->batch, c->stream); break;
+    case 16: launch_sweep_t<16>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->pass1_strip, c->pass1_lazy, (unsigned)c->batch, c->stream); break;
+    case 32: launch_sweep_t<32>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->pass1_strip, c->pass1_lazy, (unsigned)c->batch, c->stream); break;
+    case 64: launch_sweep_t<64>(a, c->flags, steps, c->solve_wgs, c->solve_waves, c->jacobi, c->pass1_lanes_max, c->scan_fine_max, c->pass1_strip, c->pass1_lazy, (unsigned)c->batch, c->stream); break;
     default: return bbme::fail(BBME_ERR_UNSUPPORTED, "block size %d", b);
     }
     HIP_TRY(hipGetLastError());
@@ -628,6 +634,7 @@ int bbme_create_batch(const bbme_params *params, int width, int height, int devi
     if (const char *e = getenv("BBME_SCAN_FINE_MAX")) c->scan_fine_max = atoll(e);
     if (const char *e = getenv("BBME_PASS1_STRIP")) c->pass1_strip = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("BBME_LIST_SPLIT")) c->list_split = atoi(e) != 0;
+    if (const char *e = getenv("BBME_PASS1_LAZY")) c->pass1_lazy = atoi(e) != 0;
     if (const char *e = getenv("BBME_SEARCH_SPLIT_BLOCKS")) { c->split_blocks = std::max(0, atoi(e)); c->split_forced = true; }
     if (const char *e = getenv("BBME_NO_GRAPH")) c->use_graph = atoi(e) == 0;
     if (const char *e = getenv("BBME_SPECULATE")) c->speculate = atoi(e) != 0;

@@ -791,6 +791,8 @@ struct RegArgs {
     unsigned long long *memo;
     int memo_init;              // 1: the memo holds nothing for this (level, block size) yet -- pass 1 writes every slot and reads none
     int memo_forward;           // 1: a block that changes leaves its dependants' SADs of the new value in their slots (forward_sads)
+    int lazy;                   // k_reg_pass1_strip, when a relaxation launch follows: blocks that need their images are not evaluated
+                                // but flagged (estimate = old value meanwhile) -- the relaxation's first round evaluates them, densely
     int stats;                  // 1: the solver's waves add their counts to counters[4], [7..12] -- stage calls only: several hundred
                                 // waves adding to the same few words is a queue at the memory side that the pyramid need not stand in
     // batch (blockIdx.y = pair): element strides from pair to pair of the per-pair buffers; counters: 64 words
@@ -1508,6 +1510,22 @@ __global__ __launch_bounds__(256) void k_reg_pass1_strip(RegArgs a)
         // nine equal candidates: the block keeps its vector (:648-660); the others get theirs below, this is their old value meanwhile
         struct __attribute__((aligned(16))) out_t { uint32_t v[4]; };
         *reinterpret_cast<out_t *>(a.est + cell0) = out_t{{own[0], own[1], own[2], own[3]}};
+    }
+    if (a.lazy) {
+        // a relaxation launch follows: it evaluates flagged blocks tile by tile with every lane busy, so the blocks that need their
+        // images are handed to it as they are -- old value as the estimate, flag set.  The field the sweep converges to is the same:
+        // every block that is not flagged has nine equal candidates (its estimate is final unless a neighbour changes, which marks it),
+        // every other block is evaluated at least once.
+        if (valid && need) {
+            const bool interior = need != 0xfu || (r >= 1 && r + 1 < a.rows && c0 >= 4 && c0 + 4 < a.cols);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if ((need >> j) & 1u) {
+                    if (!interior) a.est[cell0 + j] = a.old_grid[(size_t)(r >> a.old_shift) * a.old_cols + ((c0 + j) >> a.old_shift)];
+                    a.flag_next[cell0 + j] = 1;
+                }
+        }
+        return;
     }
     // the wave's list of blocks for the image path: ranks from four ballots
     uint32_t total = 0;

@@ -280,6 +280,14 @@ def test_stagewise_parity_with_the_strip_form_of_pass_1(bbme, oracle, monkeypatc
     compare_stagewise(bbme, oracle, n1, n2, [24, 24], [4, 4])         # unrelated frames: nearly every block takes the image path
     z = np.zeros((96, 160), np.uint8)
     compare_stagewise(bbme, oracle, z, z, [16, 16], [4, 4])           # flat: none does
+    # with a relaxation launch behind pass 1 the strip kernel evaluates nothing itself (RegArgs::lazy): the blocks that need their
+    # images keep their old value, are flagged, and the relaxation's first round evaluates them
+    monkeypatch.setenv("BBME_RELAX_STEPS", "1")
+    f1, f2, _ = bbme.synth_pair(384, 256, 6163, max_motion=14)
+    compare_stagewise(bbme, oracle, f1, f2, [48, 48, 48], [16, 16, 16])
+    compare_stagewise(bbme, oracle, n1, n2, [24, 24], [4, 4])
+    monkeypatch.setenv("BBME_RELAX_STEPS", "3")
+    compare_stagewise(bbme, oracle, n1, n2, [24, 24], [8, 8])
 
 
 def test_stagewise_parity_with_relaxation_steps(bbme, oracle, monkeypatch):
