@@ -41,7 +41,10 @@ def _big_case(rng):
     return f1, f2, search, blocks
 SETTINGS = [{}, {"BBME_MEMO_MIN_B": "8", "BBME_MEMO_FORWARD": "1"}, {"BBME_MEMO_FORWARD": "1", "BBME_SPEC_MIN_GABS": "0"},
             {"BBME_MEMO": "0", "BBME_SPEC_MIN_GABS": "0", "BBME_LIST_SPLIT": "0"},
-            {"BBME_SOLVE_WGS": "1", "BBME_SOLVE_WAVES": "1", "BBME_MEMO_MIN_B": "8"}]
+            {"BBME_SOLVE_WGS": "1", "BBME_SOLVE_WAVES": "1", "BBME_MEMO_MIN_B": "8"},
+            {"BBME_PASS1_STRIP": "1", "BBME_PASS1_LANES_MAX": "0"},
+            {"BBME_PASS1_LANES_MAX": "0", "BBME_RELAX_STEPS": "1"},            # lazy pass 1 in front of a relaxation launch, every sweep
+            {"BBME_PASS1_LAZY": "0", "BBME_PASS1_LANES_MAX": "0", "BBME_RELAX_STEPS": "2"}]
 ran = bad = 0
 t0 = time.time()
 for seed in range(first, first + n):
