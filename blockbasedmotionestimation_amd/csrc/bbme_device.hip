@@ -700,7 +700,25 @@ int bbme_create_batch(const bbme_params *params, int width, int height, int devi
             (err = hipMemset(L.img1, 0, P * plane)) != hipSuccess || (err = hipMemset(L.img2, 0, P * plane)) != hipSuccess ||
             (err = hipMemcpy(L.spiral, packed.data(), packed.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
             return cleanup_fail(bbme::fail(BBME_ERR_HIP, "allocating level %d: %s", l, hipGetErrorString(err)));
-        if (L.block == 8 || L.block == 16 || L.block == 32) {
+        if (!((L.block == 8 || L.block == 16 || L.block == 32) && L.range <= 63)) {
+            // the generic kernel (block 4 / 64, or a range beyond the strip kernel's packed keys): its window may need more LDS
+            // than a kernel gets by default
+            if (L.lds_bytes > 48 * 1024) {
+                if (L.lds_bytes > 160 * 1024)
+                    return cleanup_fail(bbme::fail(BBME_ERR_UNSUPPORTED, "level %d: a %dx%d block with range %d needs %zu bytes of LDS", l,
+                                                   L.block, L.block, L.range, L.lds_bytes));
+                const int bytes = (int)L.lds_bytes;
+                switch (L.block) {
+                case 4:  err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_search_generic<4>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); break;
+                case 8:  err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_search_generic<8>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); break;
+                case 16: err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_search_generic<16>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); break;
+                case 32: err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_search_generic<32>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); break;
+                default: err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_search_generic<64>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); break;
+                }
+                if (err != hipSuccess)
+                    return cleanup_fail(bbme::fail(BBME_ERR_HIP, "level %d: %zu bytes of LDS for the search window: %s", l, L.lds_bytes, hipGetErrorString(err)));
+            }
+        } else {
             // the strip kernel reads rank rows dy0 .. dy0+S-1 as 4 x u16 per column group
             SearchPlan plan = plan_search(L.range, L.block, L.block == 32 ? 8 : 16);
             L.fast = true;

@@ -56,8 +56,10 @@ int validate_params(const bbme_params &p)
         if (p.search_size[i] <= 0)
             return fail(BBME_ERR_INVALID, "search_size[%d]=%d must be positive", i, p.search_size[i]);
         int range = (p.search_size[i] - p.block_size[i]) >> 1;
-        if (range > 63)
-            return fail(BBME_ERR_UNSUPPORTED, "search range %d at level %d exceeds 63", range, i);
+        // (ranks of the spiral walk are 16-bit: (2 * 127 + 1)^2 - 1 < 0xffff.  Ranges up to 63 take the strip kernel where the block
+        // size allows, larger ones the generic kernel)
+        if (range > 127)
+            return fail(BBME_ERR_UNSUPPORTED, "search range %d at level %d exceeds 127", range, i);
     }
     return BBME_OK;
 }

@@ -58,6 +58,11 @@ CASES = [
     (384, 384, [158], [32], 1021, 60),                          # B=32, R=63 (largest supported)
     (384, 256, [134], [8], 1022, 60),                           # B=8, R=63
     (384, 256, [142], [16], 1023, 60),                          # B=16, R=63
+    # ranges beyond the strip kernel's packed keys (R > 63) take the generic kernel, whose window then needs more LDS than a kernel
+    # gets by default (r04; the reference takes any search size, motion_framework.cpp:296-422)
+    (384, 256, [16 + 2 * 64], [16], 1025, 60),                  # B=16, R=64: the first range past the strip kernel
+    (320, 256, [8 + 2 * 100, 8 + 2 * 70], [8, 8], 1026, 70),    # B=8, R=100 over R=70
+    (384, 384, [32 + 2 * 127], [32], 1027, 100),                # B=32, R=127 (largest supported): 286-row window, 87 KB of LDS
     # the author's second literal set (main_class.cpp:15-17, commented out there) on the 584 x 388 Middlebury geometry:
     # 32 x 32 blocks over 16 x 16 ones (search_prediction's mixed-size path) and an odd shift, 42 - 32 = 10 -> R = 5
     (584, 388, [32, 32, 42], [16, 16, 32], 1024, 10),
@@ -216,6 +221,17 @@ def test_non_convergence_is_an_error(bbme):
     ok = bbme.MF(f1, f2, search, block, 2)
     assert np.array_equal(ok.calcMotionBlockMatching(), expect)
     ok.close()
+
+
+def test_kernel_limits_are_refused(bbme):
+    """What the kernels do not take is refused when the context is created (BBME_ERR_UNSUPPORTED), not computed wrongly: a search
+    range beyond 127 (the spiral ranks are 16-bit), a block size that is not a power of two in 4..64."""
+    from blockbasedmotionestimation_amd import _capi
+    f = np.zeros((256, 384), np.uint8)
+    for search, block in (([16 + 2 * 128], [16]), ([40], [12]), ([20], [2]), ([200], [128])):
+        with pytest.raises(_capi.BbmeError) as err:
+            bbme.MF(f, f, search, block, 1)
+        assert err.value.status == _capi.ERR_UNSUPPORTED, (search, block, err.value.message)
 
 
 def test_flat_and_zero_frames_tie_breaking(bbme, oracle):
