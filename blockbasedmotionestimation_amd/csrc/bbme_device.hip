@@ -314,6 +314,7 @@ int launch_search(bbme_ctx *c, int level, int mode = kSearchPlain, hipStream_t s
         const int nblocks = (L.width / L.block) * (L.height / L.block);
         const size_t lds = std::max(L.lds_bytes, lds_floor);
         switch (L.block) {
+        case 2:  launch_search_t<2>(a, nblocks, c->batch, lds, stream); break;
         case 4:  launch_search_t<4>(a, nblocks, c->batch, lds, stream); break;
         case 8:  launch_search_t<8>(a, nblocks, c->batch, lds, stream); break;
         case 16: launch_search_t<16>(a, nblocks, c->batch, lds, stream); break;
@@ -612,6 +613,12 @@ int bbme_create_batch(const bbme_params *params, int width, int height, int devi
                               "level %d is %dx%d with %dx%d blocks: fewer than two blocks in a dimension "
                               "is undefined behaviour in the reference", l, w, h, b, b);
     }
+    // the kernels move level rows as dwords (pitch == level width): with blocks of 4 x 4 and more every level width is a multiple
+    // of four by construction, with 2 x 2 blocks it need not be
+    for (int l = 0; l < nl; ++l)
+        if ((g.padded_width >> l) % 4 != 0)
+            return bbme::fail(BBME_ERR_UNSUPPORTED, "level %d is %d pixels wide: the kernels need level widths that are multiples of 4 "
+                                                     "(2x2 blocks on a frame this narrow)", l, g.padded_width >> l);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return bbme::fail(BBME_ERR_HIP, "no HIP device available (this library has no CPU fallback)");
@@ -709,6 +716,7 @@ int bbme_create_batch(const bbme_params *params, int width, int height, int devi
                                                    L.block, L.block, L.range, L.lds_bytes));
                 const int bytes = (int)L.lds_bytes;
                 switch (L.block) {
+                case 2:  err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_search_generic<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); break;
                 case 4:  err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_search_generic<4>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); break;
                 case 8:  err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_search_generic<8>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); break;
                 case 16: err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_search_generic<16>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); break;

@@ -49,9 +49,9 @@ int validate_params(const bbme_params &p)
     if (p.num_levels <= 0 || p.num_levels > BBME_MAX_LEVELS)      // assert(num_levels > 0), :7
         return fail(BBME_ERR_INVALID, "num_levels must be in 1..%d (got %d)", BBME_MAX_LEVELS, p.num_levels);
     for (int i = 0; i < p.num_levels; ++i) {
-        if (!is_pow2(p.block_size[i]) || p.block_size[i] < 4 || p.block_size[i] > 64)
+        if (!is_pow2(p.block_size[i]) || p.block_size[i] < 2 || p.block_size[i] > 64)
             return fail(BBME_ERR_UNSUPPORTED,
-                        "block_size[%d]=%d: the kernels need a power of two in 4..64 "
+                        "block_size[%d]=%d: the kernels need a power of two in 2..64 "
                         "(the regulariser halves blocks down to 2x2)", i, p.block_size[i]);
         if (p.search_size[i] <= 0)
             return fail(BBME_ERR_INVALID, "search_size[%d]=%d must be positive", i, p.search_size[i]);

@@ -126,9 +126,16 @@ __global__ __launch_bounds__(64) void k_search_generic(SearchArgs a)
             w = *reinterpret_cast<const uint32_t *>(a.image2 + (size_t)y * a.width + x);
         win[idx] = w;
     }
-    for (int idx = lane; idx < B * BW; idx += 64) {
-        const int row = idx / BW, k = idx - row * BW;
-        cur[idx] = *reinterpret_cast<const uint32_t *>(a.image1 + (size_t)(i + row) * a.width + j + 4 * k);
+    if constexpr (B >= 4) {
+        for (int idx = lane; idx < B * BW; idx += 64) {
+            const int row = idx / BW, k = idx - row * BW;
+            cur[idx] = *reinterpret_cast<const uint32_t *>(a.image1 + (size_t)(i + row) * a.width + j + 4 * k);
+        }
+    } else {
+        // 2 x 2 blocks (r04): the block is one dword, row 0 in the low half and row 1 in the high half
+        if (lane == 0)
+            cur[0] = (uint32_t)*reinterpret_cast<const uint16_t *>(a.image1 + (size_t)i * a.width + j) |
+                     (uint32_t)*reinterpret_cast<const uint16_t *>(a.image1 + (size_t)(i + 1) * a.width + j) << 16;
     }
     __syncthreads();
 
@@ -138,6 +145,11 @@ __global__ __launch_bounds__(64) void k_search_generic(SearchArgs a)
         const int k0 = ox >> 2, sh = ox & 3;
         const uint32_t *wrow = win + (dy + R) * a.pitch_dw + k0;
         uint32_t sad = 0;
+        if constexpr (B == 2) {
+            const uint32_t r0 = __builtin_amdgcn_alignbyte(wrow[1], wrow[0], sh) & 0xffffu;
+            const uint32_t r1 = __builtin_amdgcn_alignbyte(wrow[a.pitch_dw + 1], wrow[a.pitch_dw], sh) << 16;
+            return __builtin_amdgcn_sad_u8(cur[0], r0 | r1, 0u);
+        }
 #pragma unroll 2
         for (int r = 0; r < B; ++r) {
             uint32_t lo = wrow[0];

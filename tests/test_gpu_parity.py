@@ -63,6 +63,11 @@ CASES = [
     (384, 256, [16 + 2 * 64], [16], 1025, 60),                  # B=16, R=64: the first range past the strip kernel
     (320, 256, [8 + 2 * 100, 8 + 2 * 70], [8, 8], 1026, 70),    # B=8, R=100 over R=70
     (384, 384, [32 + 2 * 127], [32], 1027, 100),                # B=32, R=127 (largest supported): 286-row window, 87 KB of LDS
+    # 2 x 2 blocks as a level's own block size (r04; the generic search kernel with the block in one dword): alone, under 4 x 4, and
+    # between two levels of larger blocks (copyMVs from a level that is already at 2 x 2 cells when its search ends)
+    (128, 96, [10], [2], 1028, 3),
+    (160, 128, [12, 20], [2, 4], 1029, 4),
+    (192, 128, [14, 10, 24], [4, 2, 8], 1030, 5),
     # the author's second literal set (main_class.cpp:15-17, commented out there) on the 584 x 388 Middlebury geometry:
     # 32 x 32 blocks over 16 x 16 ones (search_prediction's mixed-size path) and an odd shift, 42 - 32 = 10 -> R = 5
     (584, 388, [32, 32, 42], [16, 16, 32], 1024, 10),
@@ -106,9 +111,10 @@ def test_golden_fixtures(bbme, name):
 def _random_case(rng):
     """A random legal configuration and frame pair (small enough for the oracle to take milliseconds)."""
     levels = int(rng.integers(1, 4))
-    blocks = [int(rng.choice([4, 8, 16, 32])) for _ in range(levels)]
-    # sizes that need no padding keep the search for a legal size trivial; padding is tested elsewhere
-    m = int(np.lcm.reduce([b << i for i, b in enumerate(blocks)]))
+    blocks = [int(rng.choice([2, 4, 4, 8, 8, 16, 16, 32])) for _ in range(levels)]
+    # sizes that need no padding keep the search for a legal size trivial; padding is tested elsewhere; every level's width a
+    # multiple of four (the kernels move rows as dwords: only 2 x 2 blocks can ask for less)
+    m = int(np.lcm.reduce([b << i for i, b in enumerate(blocks)] + [4 << (levels - 1)]))
     w = m * int(rng.integers(max(2, -(-2 * (blocks[-1] << (levels - 1)) // m)), 6))
     h = m * int(rng.integers(max(2, -(-2 * (blocks[-1] << (levels - 1)) // m)), 5))
     w, h = min(w, 768), min(h, 512)
@@ -225,13 +231,17 @@ def test_non_convergence_is_an_error(bbme):
 
 def test_kernel_limits_are_refused(bbme):
     """What the kernels do not take is refused when the context is created (BBME_ERR_UNSUPPORTED), not computed wrongly: a search
-    range beyond 127 (the spiral ranks are 16-bit), a block size that is not a power of two in 4..64."""
+    range beyond 127 (the spiral ranks are 16-bit), a block size that is not a power of two in 2..64."""
     from blockbasedmotionestimation_amd import _capi
     f = np.zeros((256, 384), np.uint8)
-    for search, block in (([16 + 2 * 128], [16]), ([40], [12]), ([20], [2]), ([200], [128])):
+    for search, block in (([16 + 2 * 128], [16]), ([40], [12]), ([20], [1]), ([200], [128])):
         with pytest.raises(_capi.BbmeError) as err:
             bbme.MF(f, f, search, block, 1)
         assert err.value.status == _capi.ERR_UNSUPPORTED, (search, block, err.value.message)
+    # 2 x 2 blocks on a frame whose width is not a multiple of four: the kernels move rows as dwords
+    with pytest.raises(_capi.BbmeError) as err:
+        bbme.MF(f[:, :130], f[:, :130], [10], [2], 1)
+    assert err.value.status == _capi.ERR_UNSUPPORTED and "multiples of 4" in err.value.message
 
 
 def test_flat_and_zero_frames_tie_breaking(bbme, oracle):

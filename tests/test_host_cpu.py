@@ -275,7 +275,7 @@ def test_flow_errors_raise_instead_of_exit(bbme, tmp_path):
 
 
 def test_parameter_validation(bbme):
-    for search, block in [([30], [12]), ([30], [2]), ([30], [128]), ([0], [16]), ([400], [16])]:
+    for search, block in [([30], [12]), ([30], [1]), ([30], [128]), ([0], [16]), ([400], [16])]:
         with pytest.raises(bbme.BbmeError):
             bbme.plan_padding(640, 480, search, block)
     with pytest.raises(ValueError):
