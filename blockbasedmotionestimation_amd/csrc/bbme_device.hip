@@ -103,6 +103,7 @@ struct bbme_ctx {
     int local_rounds = 8;                         // k_reg_iter: heavy rounds of a tile per launch; BBME_LOCAL_ROUNDS
     int wide_threshold = 16;                      // solver: queue length above which a round takes the throughput form; BBME_WIDE_THRESHOLD
     int solve_waves = 4;                          // waves per solver workgroup (1, 2 or 4); BBME_SOLVE_WAVES
+    bool solve_share = true;                      // k_reg_solve: idle waves of a workgroup take a sibling's surplus; BBME_SOLVE_SHARE=0
     int solve_wgs = 256;                          // most workgroups of k_reg_solve (4 independent waves each); r04: 256 measured 1.5 % ahead of 128 (one wave per SIMD)
     int xcd_remap = 1;                            // XCD-aware block order in k_search_fast; BBME_XCD_REMAP
     bool jacobi = false;                          // opt-in, not bit-exact: Jacobi sweeps (pass 1 only); bbme_set_regularizer_mode
@@ -438,6 +439,7 @@ int launch_sweep(bbme_ctx *c, int level, int b, int mult, bool stats = false)
     a.round_cap = c->round_cap > 0 ? (uint32_t)c->round_cap : 64u * (uint32_t)(2 * a.rows + a.cols + 16);
     a.counters = c->counters;
     a.stats = stats ? 1 : 0;
+    a.share = c->solve_share ? 1 : 0;
     // the SAD memo: sweeps at b >= 8 whose pass 1 runs in the chain form (it is what fills the slots); the first sweep at a
     // (level, block size) finds nothing in it and rewrites every slot
     const long long nblk_memo = (long long)a.rows * a.cols;
@@ -456,9 +458,11 @@ int launch_sweep(bbme_ctx *c, int level, int b, int mult, bool stats = false)
     if (steps < 0) {
         // BBME_RELAX_RULE="min_blocks,max_b,steps_first,steps_second" (tuning knob)
         // (r03: no relaxation launch in front of the second sweep at a block size -- it changes little, and the launch cost more
-        // than it took off the solver: 1.760 -> 1.735 ms per cfg3 pair)
+        // than it took off the solver: 1.760 -> 1.735 ms per cfg3 pair; r04: nor at 4 x 4 -- with the memo-less solver of this
+        // round the chain form takes those sweeps' first generations faster than a 40 us launch does: cfg3 1.566 -> 1.547 ms,
+        // cfg4 1.605 -> 1.585 ms, interleaved medians of 5 / 4 runs)
         static long long min_blocks = 100000;
-        static int max_b = 4, s1 = 1, s2 = 0;
+        static int max_b = 2, s1 = 1, s2 = 0;
         static const bool parsed = [] {
             if (const char *e = getenv("BBME_RELAX_RULE")) sscanf(e, "%lld,%d,%d,%d", &min_blocks, &max_b, &s1, &s2);
             return true;
@@ -630,6 +634,7 @@ int bbme_create_batch(const bbme_params *params, int width, int height, int devi
     c->batch = pairs;
     const size_t P = (size_t)pairs;
     auto round64 = [](size_t n) { return (n + 63) / 64 * 64; };
+    if (const char *e = getenv("BBME_SOLVE_SHARE")) c->solve_share = atoi(e) != 0;
     if (const char *e = getenv("BBME_SOLVE_WGS")) c->solve_wgs = std::max(1, std::min(8192, atoi(e)));
     if (const char *e = getenv("BBME_RELAX_STEPS")) c->relax_steps = std::max(0, std::min(64, atoi(e)));
     if (const char *e = getenv("BBME_SOLVE_WAVES")) { const int v = atoi(e); c->solve_waves = v <= 1 ? 1 : (v == 2 ? 2 : 4); }

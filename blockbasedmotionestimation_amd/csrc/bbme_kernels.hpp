@@ -805,6 +805,7 @@ struct RegArgs {
     int memo_forward;           // 1: a block that changes leaves its dependants' SADs of the new value in their slots (forward_sads)
     int lazy;                   // k_reg_pass1_strip, when a relaxation launch follows: blocks that need their images are not evaluated
                                 // but flagged (estimate = old value meanwhile) -- the relaxation's first round evaluates them, densely
+    int share;                  // solver: a wave whose queue holds more than a round takes hands the surplus to idle waves of its workgroup
     int stats;                  // 1: the solver's waves add their counts to counters[4], [7..12] -- stage calls only: several hundred
                                 // waves adding to the same few words is a queue at the memory side that the pyramid need not stand in
     // batch (blockIdx.y = pair): element strides from pair to pair of the per-pair buffers; counters: 64 words
@@ -1762,6 +1763,33 @@ __device__ __forceinline__ void drain_lists(const RegArgs &a, int t, int nthread
     }
 }
 
+// k_reg_solve, a wave with nothing left: announce it, wait for a sibling's surplus (returns how many blocks arrived in the wave's
+// mailbox) or for the last wave to fall idle (returns 0).  Kept out of line: inlined, its spin loop sits inside the solver's round loop
+// as far as the register allocator is concerned and costs the rounds 30 scalar spills.
+__device__ __attribute__((noinline)) uint32_t solver_wait_idle(uint32_t *mail, uint32_t *idle_mask, uint32_t *done, uint32_t wave, uint32_t wpw,
+                                                               uint32_t *error_flag)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t bit = 1u << wave, full = (1u << wpw) - 1u;
+    uint32_t old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_or(idle_mask, bit, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if ((old | bit) == full) {
+        if (lane == 0) __hip_atomic_store(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return 0;
+    }
+    for (uint32_t spin = 0;; ++spin) {
+        const uint32_t got = __builtin_amdgcn_readfirstlane(__hip_atomic_load(mail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (got) return got;
+        if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP))) return 0;
+        if (spin > (1u << 20)) {                                      // an exit every wave reaches: reported, and everyone leaves
+            if (lane == 0) { *error_flag = 1; __hip_atomic_store(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+            return 0;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
 // Asynchronous solver.  Every wave owns a private LDS queue.  It scans its share of the dirty flags
 // (blocks one of whose already-updated inputs was changed by pass 1 or by the last relaxation step),
 // claims and queues the marked blocks, and whatever its own changes make stale it queues locally too
@@ -1788,13 +1816,27 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
     constexpr int NBW = 64 / LPBW;
     constexpr int NBL = 4;
     constexpr uint32_t QCAP = 1024;
-    __shared__ uint32_t qmem[4][QCAP];
+    constexpr uint32_t MAILCAP = 64;
+    // Handing surplus blocks to idle sibling waves (below): not at b = 8, where the longest waves of a sweep walk pure chains (no
+    // round of theirs leaves a block waiting, scripts/sweep_timeline.py) and the code's mere presence costs the round 50 ns.
+    constexpr bool SHARE = BS != 8;
+    // (four waves, 17.4 KB of LDS: eight waves -- 34 KB -- shared no better, and a workgroup of that size no longer fits the holes that
+    // the 20 KB workgroups of a speculative search leave: measured, the step lost its whole overlap)
+    constexpr int MAXW = 4;                                // most waves of a workgroup
+    __shared__ uint32_t qmem[MAXW][QCAP];
+    __shared__ uint32_t s_mail[MAXW][MAILCAP + 1];            // [w][0]: blocks handed to wave w, [w][1..]: their indices
+    __shared__ uint32_t s_idle, s_done;                    // bit w: wave w has nothing to do and may be handed blocks; all waves idle
     __shared__ uint32_t s_ticket;
     __builtin_amdgcn_s_setprio(2);
     shift_pair(a, blockIdx.y);
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (uniform, and the compiler is told so: it steers branches)
     uint32_t *q = qmem[wave];
+    if (SHARE && a.share && blockDim.x > 64) {             // (uniform over the launch)
+        if (threadIdx.x < MAXW) s_mail[threadIdx.x][0] = 0;
+        if (threadIdx.x == 0) { s_idle = 0; s_done = 0; }
+        __syncthreads();
+    }
     const uint32_t nblocks = (uint32_t)a.rows * a.cols;
     const uint32_t xcd = blockIdx.x & 7u;                  // the launch has a multiple of 8 workgroups
     const uint32_t wpw = blockDim.x >> 6;                  // waves per workgroup (1, 2 or 4)
@@ -1804,7 +1846,7 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
     uint32_t *ovf_list = a.list0;
     uint32_t *ovf_count = &a.counters[1];
     uint32_t head = 0, tail = 0;                  // wave-uniform, free-running
-    uint32_t evaluated = 0, rounds = 0;
+    uint32_t evaluated = 0, rounds = 0, backlog = 0;       // backlog: rounds that left queued blocks waiting
 #ifdef BBME_PHASE_PROFILE
     PhaseProf prof_s = {};
     PhaseProf *prof = nullptr;
@@ -1832,39 +1874,77 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
     const LaneGeom lgeom = lanes_geometry(a, lane & 15, BBME_NEW_MASK);      // chain form: lane k of a group = candidate k
     MemoStats mstats;
 
-    for (uint32_t k = 0;; ++k) {
-        if (seg_begin + k * 64u * Wx + wx < seg_end) {
-            const uint32_t sg = seg_begin + (k * 64u + (uint32_t)lane) * Wx + wx;
-            // SEG = 4 on small grids: a cluster of stale blocks in a row is dealt to four times as many waves
-            uint4 f = make_uint4(0, 0, 0, 0);
-            uint8_t *fp = a.flag_cur + (size_t)sg * SEG;                               // the map is padded to whole 16-flag segments
-            if (sg < seg_end) {
-                if constexpr (SEG == 16) f = *reinterpret_cast<uint4 *>(fp);
-                else f.x = *reinterpret_cast<uint32_t *>(fp);
-            }
-            const bool any = (f.x | f.y | f.z | f.w) != 0;
-            if (__ballot(any)) {
-                if (any) {
-                    if constexpr (SEG == 16) *reinterpret_cast<uint4 *>(fp) = make_uint4(0, 0, 0, 0);
-                    else *reinterpret_cast<uint32_t *>(fp) = 0u;
+    // One loop: an iteration is a scan step, a wait for a sibling's surplus, or a round.  (Scan steps and the wait sit in front of
+    // the round, behind `queue empty`, rather than around an inner loop of rounds: the round is the path a lone wave walks
+    // thousands of times, and it is laid out -- and its registers are allocated -- as the loop's straight line.)
+    uint32_t k = 0;
+    for (;;) {
+        if (head == tail) {
+            if (seg_begin + k * 64u * Wx + wx < seg_end) {
+                const uint32_t sg = seg_begin + (k * 64u + (uint32_t)lane) * Wx + wx;
+                ++k;
+                // SEG = 4 on small grids: a cluster of stale blocks in a row is dealt to four times as many waves
+                uint4 f = make_uint4(0, 0, 0, 0);
+                uint8_t *fp = a.flag_cur + (size_t)sg * SEG;                               // the map is padded to whole 16-flag segments
+                if (sg < seg_end) {
+                    if constexpr (SEG == 16) f = *reinterpret_cast<uint4 *>(fp);
+                    else f.x = *reinterpret_cast<uint32_t *>(fp);
                 }
-                const uint32_t fw[4] = {f.x, f.y, f.z, f.w};
-                // every claim of the step in flight at once (one memory trip), then the queue
-                uint32_t was[SEG];
+                const bool any = (f.x | f.y | f.z | f.w) != 0;
+                if (__ballot(any)) {
+                    if (any) {
+                        if constexpr (SEG == 16) *reinterpret_cast<uint4 *>(fp) = make_uint4(0, 0, 0, 0);
+                        else *reinterpret_cast<uint32_t *>(fp) = 0u;
+                    }
+                    const uint32_t fw[4] = {f.x, f.y, f.z, f.w};
+                    // every claim of the step in flight at once (one memory trip), then the queue
+                    uint32_t was[SEG];
 #pragma unroll
-                for (int j = 0; j < SEG; ++j) {
-                    was[j] = 1;
-                    if ((fw[j >> 2] >> (8 * (j & 3))) & 0xffu) was[j] = own_claim(a, sg * (uint32_t)SEG + (uint32_t)j);
+                    for (int j = 0; j < SEG; ++j) {
+                        was[j] = 1;
+                        if ((fw[j >> 2] >> (8 * (j & 3))) & 0xffu) was[j] = own_claim(a, sg * (uint32_t)SEG + (uint32_t)j);
+                    }
+#pragma unroll
+                    for (int j = 0; j < SEG; ++j) enqueue(was[j] == 0, sg * (uint32_t)SEG + (uint32_t)j);
                 }
-#pragma unroll
-                for (int j = 0; j < SEG; ++j) enqueue(was[j] == 0, sg * (uint32_t)SEG + (uint32_t)j);
+                continue;
             }
-        } else if (head == tail) {
-            break;
+            // Nothing left of its own.  Alone in the workgroup (or sharing off) the wave leaves; otherwise it announces itself idle
+            // and waits for a sibling's surplus -- a flood's whole frontier is claimed by the wave that follows it, and the siblings
+            // that scanned the quiet segments beside it would otherwise have left long ago.  The last wave to fall idle ends all.
+            if (!SHARE || !a.share || wpw == 1) break;
+            // (every value that steers the loop is made wave-uniform by hand: a function's result, an LDS load are divergent to the
+            // compiler, and one divergent exit turns the whole loop's control flow -- head, tail, the branches -- into vector code)
+            const uint32_t got = __builtin_amdgcn_readfirstlane(solver_wait_idle(&s_mail[wave][0], &s_idle, &s_done, (uint32_t)wave, wpw, &a.counters[5]));
+            if (!got) break;
+            // the donor cleared this wave's idle bit before it wrote the mailbox: the blocks are this wave's now (owned since claimed)
+            if ((uint32_t)lane < got) q[(tail + (uint32_t)lane) % QCAP] = s_mail[wave][1 + lane];
+            tail = __builtin_amdgcn_readfirstlane(tail + got);
+            if (lane == 0) __hip_atomic_store(&s_mail[wave][0], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            continue;
         }
-        while (head != tail) {
-            if (++rounds > round_cap) { if (lane == 0) a.counters[5] = 1; head = tail; break; }
+        {
+            if (++rounds > round_cap) { if (lane == 0) a.counters[5] = 1; head = tail; continue; }
             const bool wide = NBW > NBL && tail - head > a.wide_threshold;   // wave-uniform
+            if (__builtin_expect(SHARE && a.share && wpw > 1 && tail - head > (uint32_t)(wide ? NBW : NBL), 0)) {
+                // more queued than this round takes: deal the surplus to the idle siblings (at most MAILCAP each)
+                uint32_t idle = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                uint32_t surplus = tail - head - (uint32_t)(wide ? NBW : NBL);
+                while (idle && surplus) {
+                    const uint32_t j = (uint32_t)__builtin_ctz(idle);
+                    idle &= idle - 1u;
+                    uint32_t was_idle = 0;
+                    if (lane == 0) was_idle = __hip_atomic_fetch_and(&s_idle, ~(1u << j), __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    was_idle = __builtin_amdgcn_readfirstlane(was_idle);
+                    if (!((was_idle >> j) & 1u)) continue;                    // another sibling was quicker
+                    const uint32_t share = min(MAILCAP, (surplus + (uint32_t)__popc(idle) + 1u) / ((uint32_t)__popc(idle) + 2u));
+                    // the NEWEST blocks go: the oldest stay in this round's reach
+                    if ((uint32_t)lane < share) s_mail[j][1 + lane] = q[(tail - share + (uint32_t)lane) % QCAP];
+                    tail = __builtin_amdgcn_readfirstlane(tail - share);
+                    surplus -= share;
+                    if (lane == 0) __hip_atomic_store(&s_mail[j][0], share, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
 #ifdef BBME_PHASE_PROFILE
             prof = wide ? nullptr : &prof_s;
             if (prof) prof_s.ph[6]++;
@@ -1873,6 +1953,7 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
             const int gl = wide ? LPBW : 16;                             // lanes per block this round
             const int g = lane / gl, sub = lane % gl;
             const uint32_t cnt = min((uint32_t)(wide ? NBW : NBL), tail - head);
+            backlog += (tail - head > cnt) ? 1u : 0u;
             const bool active = (uint32_t)g < cnt;
             const uint32_t x = active ? q[(head + g) % QCAP] : 0u;      // owned since it was claimed
             head = __builtin_amdgcn_readfirstlane(head + cnt);
@@ -1978,7 +2059,12 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
     if (lane == 0 && prof_s.ph[6])
         for (int i = 0; i < 7; ++i) atomicAdd(&a.counters[9 + i], prof_s.ph[i]);
 #endif
-    if (a.stats && lane == 0 && evaluated) { atomicAdd(&a.counters[4], evaluated); atomicMax(&a.counters[7], rounds); atomicAdd(&a.counters[8], rounds); }
+    if (a.stats && lane == 0 && evaluated) {
+        atomicAdd(&a.counters[4], evaluated); atomicMax(&a.counters[7], rounds); atomicAdd(&a.counters[8], rounds);
+#ifndef BBME_PHASE_PROFILE
+        atomicMax(&a.counters[13], rounds << 16 | min(backlog, 0xffffu)); atomicAdd(&a.counters[14], backlog);
+#endif
+    }
 #ifndef BBME_PHASE_PROFILE
     if constexpr (MEMO) {
         if (a.stats && lane == 0 && mstats.lookups) {

@@ -269,7 +269,9 @@ int bbme_stage_expand(bbme_ctx *ctx);
  * re-evaluated by the solver, [5] non-convergence flag, [7] most rounds run by one wave,
  * [8] rounds summed over waves; sweeps with the SAD memo (block >= 8): [9] candidate look-ups
  * of the chain rounds, [10] of them not in the memo, [11] group passes that summed those,
- * [12] changes whose dependants' SADs were forwarded.  [4] and [7..12] are only counted by
+ * [12] changes whose dependants' SADs were forwarded; [13] (rounds << 16 | rounds that left
+ * queued blocks waiting) of the wave with the most rounds, [14] such rounds summed over waves
+ * (how much of a sweep is queueing rather than a dependency chain).  [4] and [7..14] are only counted by
  * sweeps run through bbme_stage_regularize (hundreds of waves adding to the same words is a
  * queue at the memory side that bbme_estimate does not stand in); [3] and [5] always. */
 int bbme_sweep_stats(bbme_ctx *ctx, unsigned *stats16);

@@ -44,7 +44,10 @@ SETTINGS = [{}, {"BBME_MEMO_MIN_B": "8", "BBME_MEMO_FORWARD": "1"}, {"BBME_MEMO_
             {"BBME_SOLVE_WGS": "1", "BBME_SOLVE_WAVES": "1", "BBME_MEMO_MIN_B": "8"},
             {"BBME_PASS1_STRIP": "1", "BBME_PASS1_LANES_MAX": "0"},
             {"BBME_PASS1_LANES_MAX": "0", "BBME_RELAX_STEPS": "1"},            # lazy pass 1 in front of a relaxation launch, every sweep
-            {"BBME_PASS1_LAZY": "0", "BBME_PASS1_LANES_MAX": "0", "BBME_RELAX_STEPS": "2"}]
+            {"BBME_PASS1_LAZY": "0", "BBME_PASS1_LANES_MAX": "0", "BBME_RELAX_STEPS": "2"},
+            {"BBME_SOLVE_WGS": "8", "BBME_WIDE_THRESHOLD": "100000"},           # long queues: every round hands blocks to idle siblings
+            {"BBME_SOLVE_WGS": "16", "BBME_SOLVE_WAVES": "2", "BBME_WIDE_THRESHOLD": "1", "BBME_MEMO_MIN_B": "8"},
+            {"BBME_SOLVE_SHARE": "0"}]
 ran = bad = 0
 t0 = time.time()
 for seed in range(first, first + n):

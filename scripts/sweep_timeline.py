@@ -26,6 +26,9 @@ for rep in range(2):
                 w, h, _, _ = mf.level_geometry(lvl)
                 if rep: print("L%d b=%2d m=%d blocks=%8d  %7.1f us  evaluated=%8d max_rounds=%5d sum_rounds=%8d tail_passes=%d flag=%d"
                               % (lvl, b, mult, (w // b) * (h // b), dt, st[4], st[7], st[8], st[3], st[5]))
+                if rep and st[13] and not st[15]:
+                    print("      longest wave: %d rounds, %d of them with blocks left waiting in its queue; all waves: %d such rounds of %d"
+                          % (st[13] >> 16, st[13] & 0xffff, st[14], st[8]))
                 if rep and st[15]:      # a -DBBME_PHASE_PROFILE build (BBME_LIB=...): mean cycles per LANES round and phase
                     n = float(st[15])
                     print("      LANES rounds=%d  cycles/round: gather %.0f  rows+sad %.0f  smooth+argmin %.0f  store+drain %.0f  "

@@ -199,6 +199,24 @@ def test_random_configurations_twice(bbme, oracle, seed):
         c = mf.calcMotionBlockMatching()
         mf.close()
         assert np.array_equal(c, exp), "%s relaxation steps per sweep change the field" % steps
+    # r04: a solver wave hands the blocks it cannot take in a round to idle waves of its workgroup (LDS mailboxes).  With one
+    # workgroup per XCD every queue is long and every round donates: chain rounds only (mailboxes filled to their cap), and
+    # two-wave workgroups whose rounds all take the throughput form; and with the hand-over switched off
+    for env in ({"BBME_SOLVE_WGS": "8", "BBME_WIDE_THRESHOLD": "100000"},
+                {"BBME_SOLVE_WGS": "8", "BBME_SOLVE_WAVES": "2", "BBME_WIDE_THRESHOLD": "1"},
+                {"BBME_SOLVE_SHARE": "0"}):
+        os.environ.update(env)
+        try:
+            mf = bbme.MF(f1, f2, search, blocks, L)
+        finally:
+            for key in env:
+                del os.environ[key]
+        for lvl in range(L):
+            mf.set_level_planes(lvl, omf.image(lvl, 1), omf.image(lvl, 2))
+        c = mf.calcMotionBlockMatching()
+        d = mf.calcMotionBlockMatching()
+        mf.close()
+        assert np.array_equal(c, exp) and np.array_equal(d, exp), "solver setting %s changes the field" % env
 
 
 def test_non_convergence_is_an_error(bbme):
