@@ -119,7 +119,9 @@ struct bbme_ctx {
     int spec_per_cu_l0 = 0;                       // second value of BBME_SPEC_WGS_PER_CU="other,level0": the level-0 launch's own cap
     size_t spec_lds_for(int coarser_block, int level = 1) const
     {
-        int per_cu = spec_per_cu > 0 ? spec_per_cu : (coarser_block >= 16 ? 6 : 24);
+        // (r04: 7, not 6, since the level-0 search -- not the level-1 sweeps beside it, shorter now -- is what the level waits for:
+        //  cfg3 1.494 -> 1.470 ms; 8 and more cost the sweeps more than the search gains)
+        int per_cu = spec_per_cu > 0 ? spec_per_cu : (coarser_block >= 16 ? 7 : 24);
         if (level == 0 && spec_per_cu_l0 > 0) per_cu = spec_per_cu_l0;
         return ((size_t)(160 - 40) * 1024 / per_cu) / 256 * 256;
     }
@@ -460,8 +462,9 @@ int launch_sweep(bbme_ctx *c, int level, int b, int mult, bool stats = false)
         // (r03: no relaxation launch in front of the second sweep at a block size -- it changes little, and the launch cost more
         // than it took off the solver: 1.760 -> 1.735 ms per cfg3 pair; r04: nor at 4 x 4 -- with the memo-less solver of this
         // round the chain form takes those sweeps' first generations faster than a 40 us launch does: cfg3 1.566 -> 1.547 ms,
-        // cfg4 1.605 -> 1.585 ms, interleaved medians of 5 / 4 runs)
-        static long long min_blocks = 100000;
+        // cfg4 1.605 -> 1.585 ms, interleaved medians of 5 / 4 runs; and, once the solver's waves shared their queues, only on
+        // grids of >= 300 000 blocks: cfg3 1.523 -> 1.496, cfg2 0.699 -> 0.680, cfg4 1.611 -> 1.603, reference literals 1.336 -> 1.331)
+        static long long min_blocks = 300000;
         static int max_b = 2, s1 = 1, s2 = 0;
         static const bool parsed = [] {
             if (const char *e = getenv("BBME_RELAX_RULE")) sscanf(e, "%lld,%d,%d,%d", &min_blocks, &max_b, &s1, &s2);

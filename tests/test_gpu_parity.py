@@ -182,7 +182,7 @@ def test_random_configurations_twice(bbme, oracle, seed):
     c = mf.calcMotionBlockMatching()
     mf.close()
     assert np.array_equal(c, exp), "a one-wave solver changes the field"
-    # the tile-resident relaxation launches before the solver (by default only on grids of >= 100 000 blocks at b <= 4)
+    # the tile-resident relaxation launches before the solver (by default only on grids of >= 300 000 blocks at b = 2)
     # forced into every sweep: any number of them must leave the result untouched
     for steps in ("1", "3"):
         # ... and with the speculative search forced onto every level (by default only levels with >= 8 G abs-diffs of
