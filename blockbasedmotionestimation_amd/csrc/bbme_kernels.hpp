@@ -1782,7 +1782,7 @@ __device__ __attribute__((noinline)) uint32_t solver_wait_idle(uint32_t *mail, u
         const uint32_t got = __builtin_amdgcn_readfirstlane(__hip_atomic_load(mail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
         if (got) return got;
         if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP))) return 0;
-        if (spin > (1u << 20)) {                                      // an exit every wave reaches: reported, and everyone leaves
+        if (spin > (1u << 23)) {                                      // (~1 s) an exit every wave reaches: reported, and everyone leaves
             if (lane == 0) { *error_flag = 1; __hip_atomic_store(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
             return 0;
         }
@@ -1817,9 +1817,9 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
     constexpr int NBL = 4;
     constexpr uint32_t QCAP = 1024;
     constexpr uint32_t MAILCAP = 64;
-    // Handing surplus blocks to idle sibling waves (below): not at b = 8, where the longest waves of a sweep walk pure chains (no
-    // round of theirs leaves a block waiting, scripts/sweep_timeline.py) and the code's mere presence costs the round 50 ns.
-    constexpr bool SHARE = BS != 8;
+    // Handing surplus blocks to idle sibling waves (below).  (A compile-time switch for experiments: with the rounds in a flat loop the
+    // code's mere presence cost the b = 8 launches 1-3 us each; with the rounds in an inner loop of their own it costs nothing.)
+    constexpr bool SHARE = true;
     // (four waves, 17.4 KB of LDS: eight waves -- 34 KB -- shared no better, and a workgroup of that size no longer fits the holes that
     // the 20 KB workgroups of a speculative search leave: measured, the step lost its whole overlap)
     constexpr int MAXW = 4;                                // most waves of a workgroup
@@ -1874,9 +1874,8 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
     const LaneGeom lgeom = lanes_geometry(a, lane & 15, BBME_NEW_MASK);      // chain form: lane k of a group = candidate k
     MemoStats mstats;
 
-    // One loop: an iteration is a scan step, a wait for a sibling's surplus, or a round.  (Scan steps and the wait sit in front of
-    // the round, behind `queue empty`, rather than around an inner loop of rounds: the round is the path a lone wave walks
-    // thousands of times, and it is laid out -- and its registers are allocated -- as the loop's straight line.)
+    // Outer loop: with the queue empty, a scan step, or -- the scan finished -- a wait for a sibling's surplus; then rounds until the
+    // queue is empty again (an inner loop of their own: measured 1-3 us per launch ahead of one flat loop at b = 8).
     uint32_t k = 0;
     for (;;) {
         if (head == tail) {
@@ -1923,7 +1922,7 @@ __global__ __launch_bounds__(256) void k_reg_solve(RegArgs a)
             if (lane == 0) __hip_atomic_store(&s_mail[wave][0], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             continue;
         }
-        {
+        while (head != tail) {
             if (++rounds > round_cap) { if (lane == 0) a.counters[5] = 1; head = tail; continue; }
             const bool wide = NBW > NBL && tail - head > a.wide_threshold;   // wave-uniform
             if (__builtin_expect(SHARE && a.share && wpw > 1 && tail - head > (uint32_t)(wide ? NBW : NBL), 0)) {
