@@ -657,12 +657,14 @@ def test_batched_context_matches_the_oracle_pair_by_pair(bbme, oracle, w, h, sea
         assert np.array_equal(got[p], exp[p]), "pair %d (device frames)" % p
 
 
-@pytest.mark.parametrize("variant", ["generic_search", "raster", "block4", "block64"])
+@pytest.mark.parametrize("variant", ["generic_search", "raster", "block2", "block4", "block64"])
 def test_batched_context_with_the_generic_search_kernels(bbme, oracle, monkeypatch, variant):
-    """The pair as blockIdx.y of k_search_generic (block 4 and 64, the raster find_min_block variant, and BBME_GENERIC_SEARCH=1
+    """The pair as blockIdx.y of k_search_generic (block 2, 4 and 64, the raster find_min_block variant, and BBME_GENERIC_SEARCH=1
     on block sizes that normally take the strip kernel): every pair of a batched context against the oracle."""
     if variant == "block4":
         w, h, ss, bs = 200, 136, [12, 12], [4, 4]
+    elif variant == "block2":
+        w, h, ss, bs = 200, 136, [10, 12], [2, 4]
     elif variant == "block64":
         w, h, ss, bs = 512, 384, [80, 80], [64, 64]
     else:
