@@ -48,6 +48,8 @@ CASES = {
     "hotpath_mixed_l3": (192, 128, [24, 40, 30], [8, 16, 8], 2005, 8),
     # the reference's second literal set (main_class.cpp:15-17): block {16,16,32}, search {32,32,42}; 376 x 250 pads to 384 x 256
     "hotpath_ref2_l3": (376, 250, [32, 32, 42], [16, 16, 32], 2006, 8),
+    # 2 x 2 blocks as a level's own block size (level 0 here), under 4 x 4
+    "hotpath_block2_l2": (96, 64, [12, 16], [2, 4], 2007, 5),
 }
 
 

@@ -81,7 +81,7 @@ def test_stagewise_parity(bbme, oracle, w, h, search, block, seed, mm):
 
 
 @pytest.mark.parametrize("name", ["hotpath_b16_r7_l3", "hotpath_b16_r16_l2", "hotpath_b8_r32_l2",
-                                  "hotpath_b32_r16_l2", "hotpath_mixed_l3", "hotpath_ref2_l3",
+                                  "hotpath_b32_r16_l2", "hotpath_mixed_l3", "hotpath_ref2_l3", "hotpath_block2_l2",
                                   "variant_raster_b16_r7_l3", "variant_raster_b8_r32_l2", "variant_jacobi_b16_r7_l3"])
 def test_golden_fixtures(bbme, name):
     """Committed vectors (tests/golden/*.npz): planes in, every intermediate MV grid and the final

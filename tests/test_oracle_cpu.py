@@ -20,7 +20,7 @@ def load_golden(name):
 
 
 GOLDEN_CASES = ["hotpath_b16_r7_l3", "hotpath_b16_r16_l2", "hotpath_b8_r32_l2", "hotpath_b32_r16_l2",
-                "hotpath_mixed_l3", "hotpath_ref2_l3"]
+                "hotpath_mixed_l3", "hotpath_ref2_l3", "hotpath_block2_l2"]
 
 
 # ---- spiral ------------------------------------------------------------------------------------
@@ -67,7 +67,7 @@ def test_oracle_reproduces_golden_vectors(oracle, name):
     assert np.array_equal(omf2.calc_motion_block_matching(), g["flow"])
 
 
-@pytest.mark.parametrize("name", ["hotpath_b16_r7_l3", "hotpath_b8_r32_l2", "hotpath_mixed_l3", "hotpath_ref2_l3"])
+@pytest.mark.parametrize("name", ["hotpath_b16_r7_l3", "hotpath_b8_r32_l2", "hotpath_mixed_l3", "hotpath_ref2_l3", "hotpath_block2_l2"])
 def test_numpy_restatement_agrees_with_c_oracle(name):
     from oracle import bbme_numpy
     g = load_golden(name)
